@@ -1,0 +1,1153 @@
+// aura_knn.hip -- episodic-bank kernels for gfx950 (MI355X): one-shot write, row norms, decay and
+// the exact batched cosine-kNN recall (scan + top-k).
+//
+// Data layout in HBM (all fp32, row-major; names follow HippocampalFormation's buffers,
+// src/core/hippocampal.py:90-117):
+//   bank     [M][D]   memory_features          meta [M][4] = {strength, timestamp, centroid_id, 0}
+//   loc      [M][S]   memory_locations         inv_norm [M] = 1/max(||bank_i||, 1e-12)  (build-side)
+//
+// Recall = scores(Q x bank) -> per-query top-k.  For a batch of queries the score matrix is a
+// true dense contraction (2*nq*N*D FLOP over N*D*4 bytes: 127 FLOP/B at nq = 256), so the scan
+// runs on the fp32 matrix cores: v_mfma_f32_32x32x2_f32 is exact fp32 (a k-ordered fmaf chain,
+// no xf32/TF32 on gfx950) at 64 FLOP/clk/SIMD.  Each 512-thread workgroup owns a tile of bank
+// rows x up to 256 queries, streams both operands through LDS in 32-deep k-tiles (the bank is
+// read from HBM exactly once per 256-query block) and applies the reference's combined-score
+// epilogue on the accumulators.  For nq <= 32 the same kernel degenerates to an HBM-bound
+// batched GEMV (one 32-query MFMA column, 8 waves along the bank rows).
+//
+// Top-k never materialises nq x N scores on the fast path: a strided sample of bank tiles is
+// scored densely first, its exact per-query k-th best is a valid lower bound of the global k-th
+// best, and the main scan appends only (score,row) pairs that reach that bound to small
+// per-query candidate lists; an LDS radix-select + bitonic sort over those lists gives the exact
+// top-k (ties -> lower row).  The result is independent of append order.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/aura_hip.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+inline int check_launch() { return hipGetLastError() == hipSuccess ? AURA_OK : AURA_E_LAUNCH; }
+inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+// order-preserving float -> uint32 (larger float <=> larger key); -0 < +0, NaN ends up extreme
+__device__ __forceinline__ uint32_t ord_key(float f) {
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord_unkey(uint32_t k) {
+    uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(u);
+}
+
+// ------------------------------------------------------------------------------------------
+// Row norms / query norms:  inv[i] = 1 / max(||x_i||, 1e-12)   (F.normalize, hippocampal.py:273,278)
+// One wave per row, 16-byte loads.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void row_inv_norm_kernel(const float* __restrict__ x,
+                                                           float* __restrict__ inv, int64_t n,
+                                                           int64_t D) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float* p = x + row * D;
+    float s = 0.0f;
+    if ((D & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) & 15) == 0)) {
+        for (int64_t i = lane * 4; i < D; i += 256) {
+            float4 v = *reinterpret_cast<const float4*>(p + i);
+            s = fmaf(v.x, v.x, s); s = fmaf(v.y, v.y, s); s = fmaf(v.z, v.z, s); s = fmaf(v.w, v.w, s);
+        }
+    } else {
+        for (int64_t i = lane; i < D; i += 64) s = fmaf(p[i], p[i], s);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) inv[row] = 1.0f / fmaxf(sqrtf(s), 1e-12f);
+}
+
+// ------------------------------------------------------------------------------------------
+// One-shot write without centroid maintenance: independent rows, one wave per row.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bank_write_kernel(float* bank, float* loc, float* meta,
+                                                         float* inv_norm, const float* feats,
+                                                         const int64_t* slots, const float* cur_loc,
+                                                         int sdims, float now, float cid,
+                                                         int64_t n, int64_t D) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const int64_t slot = slots[i];
+    const float* src = feats + i * D;
+    float* dst = bank + slot * D;
+    float s = 0.0f;
+    for (int64_t c = lane; c < D; c += 64) {
+        float v = src[c];
+        dst[c] = v;
+        s = fmaf(v, v, s);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) {
+        inv_norm[slot] = 1.0f / fmaxf(sqrtf(s), 1e-12f);
+        float4 m = make_float4(1.0f, now, cid, 0.0f);
+        *reinterpret_cast<float4*>(meta + slot * 4) = m;
+    }
+    if (lane < sdims) loc[slot * sdims + lane] = cur_loc[lane];
+}
+
+// ------------------------------------------------------------------------------------------
+// One-shot write WITH the online centroid update of hippocampal.py:218-230.  The update is
+// order dependent (row i sees the centroids left by rows < i), so one workgroup walks the rows
+// in order; each row's 256 x D distance scan is spread over the 1024 threads (4 per centroid).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void bank_write_centroid_kernel(
+    float* bank, float* loc, float* meta, float* inv_norm, float* centroids, float* counts,
+    int eff_k, const float* feats, const int64_t* slots, const float* cur_loc, int sdims, float now,
+    int64_t n, int64_t D) {
+    __shared__ float s_dist[1024];
+    __shared__ int s_best;
+    __shared__ float s_red[16];
+    const int tid = threadIdx.x;
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t slot = slots[i];
+        const float* src = feats + i * D;
+        // distances: thread (c, part) with 4 parts per centroid
+        const int c = tid >> 2, part = tid & 3;
+        float acc = 0.0f;
+        if (c < eff_k) {
+            const float* cp = centroids + (int64_t)c * D;
+            for (int64_t j = part; j < D; j += 4) {
+                float d = cp[j] - src[j];
+                acc = fmaf(d, d, acc);
+            }
+        }
+        acc += __shfl_xor(acc, 1);
+        acc += __shfl_xor(acc, 2);
+        if (part == 0) s_dist[c] = (c < eff_k) ? sqrtf(acc) : INFINITY;
+        // copy row + norm
+        float s = 0.0f;
+        for (int64_t j = tid; j < D; j += 1024) {
+            float v = src[j];
+            bank[slot * D + j] = v;
+            s = fmaf(v, v, s);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+        if ((tid & 63) == 0) s_red[tid >> 6] = s;
+        __syncthreads();
+        if (tid == 0) {
+            float tot = 0.0f;
+            for (int w = 0; w < 16; ++w) tot += s_red[w];
+            inv_norm[slot] = 1.0f / fmaxf(sqrtf(tot), 1e-12f);
+            int best = 0;
+            float bd = s_dist[0];
+            for (int k = 1; k < eff_k && k < 256; ++k)
+                if (s_dist[k] < bd) { bd = s_dist[k]; best = k; }  // first minimum, as torch.argmin
+            s_best = best;
+            const float cnt = counts[best] + 1.0f;
+            counts[best] = cnt;
+            *reinterpret_cast<float4*>(meta + slot * 4) = make_float4(1.0f, now, (float)best, 0.0f);
+        }
+        if (tid < sdims) loc[slot * sdims + tid] = cur_loc[tid];
+        __syncthreads();
+        const int best = s_best;
+        const float eta = 1.0f / fmaxf(counts[best], 1.0f);
+        const float one_m = 1.0f - eta;
+        float* cp = centroids + (int64_t)best * D;
+        for (int64_t j = tid; j < D; j += 1024) cp[j] = one_m * cp[j] + eta * src[j];
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void bank_decay_kernel(float* meta, float factor, int64_t count) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < count) meta[i * 4] *= factor;
+}
+
+__global__ __launch_bounds__(256) void bank_gather_kernel(const float* __restrict__ bank,
+                                                          const int32_t* __restrict__ idx,
+                                                          float* __restrict__ out, int64_t n,
+                                                          int64_t D) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const int32_t r = idx[i];
+    for (int64_t c = lane; c < D; c += 64) out[i * D + c] = r >= 0 ? bank[(int64_t)r * D + c] : 0.0f;
+}
+
+// ------------------------------------------------------------------------------------------
+// Scan kernel
+// ------------------------------------------------------------------------------------------
+constexpr int SCAN_THREADS = 512;
+constexpr int BK = 32;          // k-tile depth
+constexpr int LDS_STRIDE = 36;  // floats per LDS row: 144 B keeps ds_read_b128 of 32 rows conflict-free
+constexpr int MODE_DENSE = 0;
+constexpr int MODE_FILTER = 1;
+constexpr int MODE_ASSIGN = 2;
+
+struct ScanArgs {
+    const float* bank;
+    const float* inv_norm;
+    const float* meta;
+    const float* loc;
+    const float* queries;  // [nq][D] (this query block's base already applied)
+    const float* inv_q;    // [nq]
+    const float* q_loc;    // [nq][sdims] or null
+    int sdims;
+    float now;
+    int64_t row_begin, row_end;  // scanned row range
+    int64_t D;
+    int nq;                 // queries in this block
+    int tile_step;          // DENSE: tile = blockIdx.x * tile_step; FILTER: sample tiles are skipped
+    int n_sample_tiles;     // FILTER: tiles t with t % tile_step == 0 && t / tile_step < this are skipped
+    // DENSE output
+    float* dense;           // [nq][dense_ld]; column = blockIdx.x * BR + local row
+    int64_t dense_ld;
+    // FILTER output
+    const uint32_t* thr;    // [nq] ordered keys
+    int32_t* cnt;           // [nq]
+    float* cand_scores;     // [nq][cap]
+    int32_t* cand_idx;      // [nq][cap]
+    int cap;
+    // optional centroid-candidate mask: bit c of probe_mask[q][8] set <=> centroid c is probed
+    // by query q; rows whose centroid id is not probed are not candidates (hippocampal.py:264-270)
+    const uint32_t* probe_mask;
+    // ASSIGN mode (k-means): "queries" are centroids; assign_out[row] = argmin_c(|c|^2 - 2 x.c)
+    const float* qnorm2;    // [nq]
+    int32_t* assign_out;    // [rows]
+};
+
+template <int WQ, int WR, int RT, int MODE, bool VEC4>
+__global__ __launch_bounds__(SCAN_THREADS) void knn_scan_kernel(const ScanArgs a) {
+    static_assert(WQ * WR == 8, "8 waves");
+    constexpr int BQ = WQ * 32;
+    constexpr int BR = WR * RT * 32;
+    constexpr int NV = (BQ + BR) * (BK / 4);                     // float4 slots per k-tile
+    constexpr int NLD = (NV + SCAN_THREADS - 1) / SCAN_THREADS;  // per-thread loads
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Qs = smem;                    // [BQ][LDS_STRIDE]
+    float* Bs = smem + BQ * LDS_STRIDE;  // [BR][LDS_STRIDE]
+
+    int64_t tile = blockIdx.x;
+    if (MODE == MODE_DENSE) {
+        tile *= a.tile_step;
+    } else if (a.tile_step > 0 && tile % a.tile_step == 0 && tile / a.tile_step < a.n_sample_tiles) {
+        return;  // scored densely by the sample pass
+    }
+    const int64_t row0 = a.row_begin + tile * BR;
+    const int q0 = blockIdx.y * BQ;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wq = wave % WQ, wr = wave / WQ;
+    const int li = lane & 31, lh = lane >> 5;
+    const int64_t D = a.D;
+
+    f32x16 acc[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[r][e] = 0.0f;
+
+    float4 pre[NLD];
+    auto load_tile = [&](int64_t k0) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int f = tid + i * SCAN_THREADS;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f < NV) {
+                const int r = f >> 3, c = (f & 7) * 4;
+                const int64_t k = k0 + c;
+                const float* src = nullptr;
+                if (r < BQ) {
+                    if (q0 + r < a.nq) src = a.queries + (int64_t)(q0 + r) * D + k;
+                } else {
+                    const int64_t row = row0 + (r - BQ);
+                    if (row < a.row_end) src = a.bank + row * D + k;
+                }
+                if (src) {
+                    if (VEC4) {
+                        if (k < D) v = *reinterpret_cast<const float4*>(src);
+                    } else {
+                        if (k + 0 < D) v.x = src[0];
+                        if (k + 1 < D) v.y = src[1];
+                        if (k + 2 < D) v.z = src[2];
+                        if (k + 3 < D) v.w = src[3];
+                    }
+                }
+            }
+            pre[i] = v;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int f = tid + i * SCAN_THREADS;
+            if (f < NV) {
+                const int r = f >> 3, c = (f & 7) * 4;
+                *reinterpret_cast<float4*>(smem + r * LDS_STRIDE + c) = pre[i];
+            }
+        }
+    };
+
+    const int64_t KT = (D + BK - 1) / BK;
+    load_tile(0);
+    for (int64_t kt = 0; kt < KT; ++kt) {
+        store_tile();
+        __syncthreads();
+        if (kt + 1 < KT) load_tile((kt + 1) * BK);
+        const float* qrow = Qs + (wq * 32 + li) * LDS_STRIDE + 4 * lh;
+        const float* brow = Bs + ((wr * RT) * 32 + li) * LDS_STRIDE + 4 * lh;
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            const float4 av = *reinterpret_cast<const float4*>(qrow + kk * 8);
+            float4 bv[RT];
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+                bv[r] = *reinterpret_cast<const float4*>(brow + r * 32 * LDS_STRIDE + kk * 8);
+            const float af[4] = {av.x, av.y, av.z, av.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int r = 0; r < RT; ++r) {
+                    const float bf = j == 0 ? bv[r].x : j == 1 ? bv[r].y : j == 2 ? bv[r].z : bv[r].w;
+                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j], bf, acc[r], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue on the accumulators ------------------------------------------------------
+    // lane holds bank row (li) x 16 "queries" {(e&3) + 8*(e>>2) + 4*lh} of its wave's 32
+    if (MODE == MODE_ASSIGN) {
+        // nearest centroid per bank row: argmin_c (|c|^2 - 2 x.c), ties -> lower c
+        float* red_v = smem;                                   // [WQ][BR]
+        int* red_c = reinterpret_cast<int*>(smem + WQ * BR);   // [WQ][BR]
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            float bv = INFINITY;
+            int bc = 0x7fffffff;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int c = q0 + wq * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (c < a.nq) {
+                    const float val = a.qnorm2[c] - 2.0f * acc[r][e];
+                    if (val < bv || (val == bv && c < bc)) { bv = val; bc = c; }
+                }
+            }
+            const float ov = __shfl_xor(bv, 32);
+            const int oc = __shfl_xor(bc, 32);
+            if (ov < bv || (ov == bv && oc < bc)) { bv = ov; bc = oc; }
+            if (lh == 0) {
+                const int lrow = (wr * RT + r) * 32 + li;
+                red_v[wq * BR + lrow] = bv;
+                red_c[wq * BR + lrow] = bc;
+            }
+        }
+        __syncthreads();
+        for (int t = tid; t < BR; t += SCAN_THREADS) {
+            float bv = red_v[t];
+            int bc = red_c[t];
+#pragma unroll
+            for (int w = 1; w < WQ; ++w) {
+                const float ov = red_v[w * BR + t];
+                const int oc = red_c[w * BR + t];
+                if (ov < bv || (ov == bv && oc < bc)) { bv = ov; bc = oc; }
+            }
+            const int64_t row = row0 + t;
+            if (row < a.row_end) a.assign_out[row] = bc;
+        }
+        return;
+    }
+
+    // combined score (hippocampal.py:279-303)
+    uint32_t* s_mask = reinterpret_cast<uint32_t*>(smem);  // [BQ][8], staged after the k loop
+    if (a.probe_mask) {
+        for (int t = tid; t < BQ * 8; t += SCAN_THREADS) {
+            const int q = q0 + (t >> 3);
+            s_mask[t] = q < a.nq ? a.probe_mask[(int64_t)q * 8 + (t & 7)] : 0u;
+        }
+        __syncthreads();
+    }
+    float iq[16];
+    uint32_t thr[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int q = q0 + wq * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        iq[e] = q < a.nq ? a.inv_q[q] : 0.0f;
+        thr[e] = (MODE == MODE_FILTER && q < a.nq) ? a.thr[q] : 0xffffffffu;
+    }
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+        const int lrow = (wr * RT + r) * 32 + li;
+        const int64_t row = row0 + lrow;
+        const bool vrow = row < a.row_end;
+        float inv_m = 0.f, strength = 0.f, tw = 0.f;
+        int cid = -1;
+        float lx[4] = {0.f, 0.f, 0.f, 0.f};
+        if (vrow) {
+            inv_m = a.inv_norm[row];
+            const float4 m = *reinterpret_cast<const float4*>(a.meta + row * 4);
+            strength = m.x;
+            const float age = a.now - m.y;
+            tw = 0.2f * expf(-age / 3600.0f);
+            cid = (int)m.z;
+            if (a.q_loc)
+                for (int d = 0; d < a.sdims && d < 4; ++d) lx[d] = a.loc[row * a.sdims + d];
+        }
+        const bool cid_ok = cid >= 0 && cid < 256;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int ql = wq * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            const int q = q0 + ql;
+            const float sim = acc[r][e] * iq[e] * inv_m;
+            float comb = 0.5f * sim;
+            if (a.q_loc && q < a.nq) {
+                float d2 = 0.0f;
+                for (int d = 0; d < a.sdims && d < 4; ++d) {
+                    const float df = lx[d] - a.q_loc[(int64_t)q * a.sdims + d];
+                    d2 = d2 + df * df;
+                }
+                comb = comb + 0.3f * (1.0f / (1.0f + sqrtf(d2)));
+            }
+            comb = (comb + tw) * strength;
+            bool cand = vrow && q < a.nq;
+            if (a.probe_mask)
+                cand = cand && cid_ok && ((s_mask[ql * 8 + (cid >> 5)] >> (cid & 31)) & 1u);
+            if (MODE == MODE_DENSE) {
+                if (q < a.nq)
+                    a.dense[(int64_t)q * a.dense_ld + (int64_t)blockIdx.x * BR + lrow] =
+                        cand ? comb : -INFINITY;
+            } else {
+                if (cand && ord_key(comb) >= thr[e]) {
+                    const int pos = atomicAdd(a.cnt + q, 1);
+                    if (pos < a.cap) {
+                        a.cand_scores[(int64_t)q * a.cap + pos] = comb;
+                        a.cand_idx[(int64_t)q * a.cap + pos] = (int32_t)row;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Centroid probe: for each query the `nprobe` nearest (L2, unnormalised query) of the 256
+// centroid rows -> 256-bit mask.  hippocampal.py:261-262 (topk over ALL 256 buffer rows, also
+// the zero rows beyond centroids_k).  One workgroup per query, ties -> lower centroid.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void centroid_probe_kernel(const float* __restrict__ centroids,
+                                                             const float* __restrict__ queries,
+                                                             int64_t D, int nprobe,
+                                                             uint32_t* __restrict__ mask_out) {
+    __shared__ float s_d[256];
+    __shared__ float s_bv[4];
+    __shared__ int s_bi[4];
+    __shared__ uint32_t s_m[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* q = queries + (int64_t)blockIdx.x * D;
+    for (int c = wave; c < 256; c += 4) {
+        const float* cp = centroids + (int64_t)c * D;
+        float acc = 0.0f;
+        for (int64_t j = lane; j < D; j += 64) {
+            const float d = cp[j] - q[j];
+            acc = fmaf(d, d, acc);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+        if (lane == 0) s_d[c] = sqrtf(acc);
+    }
+    if (tid < 8) s_m[tid] = 0u;
+    __syncthreads();
+    float mine = s_d[tid];
+    for (int p = 0; p < nprobe; ++p) {
+        float bv = mine;
+        int bi = tid;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(bv, off);
+            const int oi = __shfl_xor(bi, off);
+            if (ov < bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) { s_bv[wave] = bv; s_bi[wave] = bi; }
+        __syncthreads();
+        bv = s_bv[0]; bi = s_bi[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (s_bv[w] < bv || (s_bv[w] == bv && s_bi[w] < bi)) { bv = s_bv[w]; bi = s_bi[w]; }
+        if (tid == bi) { mine = INFINITY; s_m[bi >> 5] |= 1u << (bi & 31); }
+        __syncthreads();
+    }
+    if (tid < 8) mask_out[(int64_t)blockIdx.x * 8 + tid] = s_m[tid];
+}
+
+// ------------------------------------------------------------------------------------------
+// k-means helpers (rebuild_centroids, hippocampal.py:345-377)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void row_norm2_kernel(const float* __restrict__ x,
+                                                        float* __restrict__ out, int64_t n,
+                                                        int64_t D) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    float s = 0.0f;
+    for (int64_t i = lane; i < D; i += 64) s = fmaf(x[row * D + i], x[row * D + i], s);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) out[row] = s;
+}
+
+// One workgroup per centroid: mean of the rows assigned to it (fixed summation order, so the
+// result is reproducible), count, and optionally the centroid id written to meta[row][2].
+// Empty clusters keep their centroid (hippocampal.py:362-363).
+__global__ __launch_bounds__(256) void kmeans_update_kernel(const float* __restrict__ bank,
+                                                            const int32_t* __restrict__ assign,
+                                                            float* centroids, float* counts,
+                                                            float* meta, int64_t N, int64_t D,
+                                                            int update_means) {
+    extern __shared__ __attribute__((aligned(16))) float s_acc[];  // [4][D]
+    __shared__ int s_cnt[4];
+    const int c = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* acc = s_acc + (int64_t)wave * D;
+    for (int64_t j = lane; j < D; j += 64) acc[j] = 0.0f;
+    int cnt = 0;
+    // each wave walks a contiguous quarter of the rows in order; lanes cover the feature dim
+    const int64_t per = (N + 3) / 4;
+    const int64_t beg = wave * per, end = (beg + per) < N ? (beg + per) : N;
+    for (int64_t base = beg; base < end; base += 64) {
+        const int64_t r = base + lane;
+        const bool mine = r < end && assign[r] == c;
+        unsigned long long m = __ballot(mine);
+        if (mine && meta) meta[r * 4 + 2] = (float)c;
+        while (m) {
+            const int l = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const int64_t row = base + l;
+            ++cnt;
+            if (update_means)
+                for (int64_t j = lane; j < D; j += 64) acc[j] += bank[row * D + j];
+        }
+    }
+    if (lane == 0) s_cnt[wave] = cnt;
+    __syncthreads();
+    const int total = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    if (update_means && total > 0) {
+        const float inv = (float)total;
+        for (int64_t j = tid; j < D; j += 256) {
+            const float sum = ((s_acc[j] + s_acc[D + j]) + s_acc[2 * D + j]) + s_acc[3 * D + j];
+            centroids[(int64_t)c * D + j] = sum / inv;
+        }
+    }
+    if (tid == 0 && counts) counts[c] = (float)total;
+}
+
+// ------------------------------------------------------------------------------------------
+// Exact top-k select: one 256-thread workgroup per (chunk, query).  64-bit composite keys
+// (ord(score) << 32 | ~idx) make every key unique, so "k-th largest key" is exact and ties go
+// to the lower index.  MSB-first 8-bit radix select over LDS-resident keys, then the k winners
+// are either appended to a candidate list (unsorted) or bitonic-sorted and written out.
+// ------------------------------------------------------------------------------------------
+constexpr int SEL_THREADS = 256;
+constexpr int SEL_LDS_KEYS = 8192;  // 64 KiB of keys
+constexpr int SEL_MAX_K = 1024;
+
+struct SelectArgs {
+    // source element i of query q, chunk c:
+    //   score = src_scores[q*src_qs + (j / src_inner)*src_outer + j % src_inner],  j = c*chunk + i
+    //   idx   = src_idx ? src_idx[same] : dense mapping (row_begin + (j / blk)*blk*step + j % blk)
+    const float* src_scores;
+    const int32_t* src_idx;
+    int64_t src_qs, src_inner, src_outer;
+    const int32_t* src_cnt;  // per-query element count (clamped to n_max) or null -> n_max
+    int64_t n_max;           // elements per query over all chunks
+    int chunk;               // elements per chunk (grid.x chunks)
+    int blk, step;           // dense mapping
+    int64_t row_begin, row_end;
+    int k;
+    // destination
+    int sorted;              // 1: sorted output to dst[q*dst_qs + i]; 0: append block at dst[q*dst_qs + dst_off + c*k + i]
+    float* dst_scores;
+    int32_t* dst_idx;
+    int64_t dst_qs;
+    int64_t dst_off;
+    int32_t idx_base;
+    uint32_t* thr_out;       // optional: atomicMax of the chunk's k-th score key
+    int32_t* cnt_out;        // optional: atomicAdd k (append mode)
+    int32_t* overflow;       // optional: set when src_cnt > n_max
+};
+
+__global__ __launch_bounds__(SEL_THREADS) void topk_select_kernel(const SelectArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long s_keys[];  // [chunk <= SEL_LDS_KEYS]
+    __shared__ unsigned int s_hist[256];
+    __shared__ unsigned long long s_prefix;
+    __shared__ int s_remaining;
+    __shared__ unsigned long long s_win[SEL_MAX_K];
+    __shared__ int s_nwin;
+    __shared__ unsigned int s_wsum[SEL_THREADS / 64];
+
+    const int tid = threadIdx.x;
+    const int q = blockIdx.y;
+    const int c = blockIdx.x;
+    int64_t total = a.n_max;
+    if (a.src_cnt) {
+        const int64_t cnt = a.src_cnt[q];
+        if (cnt > a.n_max) {
+            if (tid == 0 && a.overflow) *a.overflow = 1;
+        } else {
+            total = cnt;
+        }
+    }
+    const int64_t j0 = (int64_t)c * a.chunk;
+    int n = (int)((total - j0) < a.chunk ? (total - j0) : a.chunk);
+    if (n < 0) n = 0;
+
+    // load keys
+    for (int i = tid; i < n; i += SEL_THREADS) {
+        const int64_t j = j0 + i;
+        const int64_t off = (int64_t)q * a.src_qs + (j / a.src_inner) * a.src_outer + j % a.src_inner;
+        float s = a.src_scores[off];
+        int64_t idx;
+        if (a.src_idx) {
+            idx = a.src_idx[off];
+        } else {
+            idx = a.row_begin + (j / a.blk) * (int64_t)a.blk * a.step + j % a.blk;
+            if (idx >= a.row_end) { s = -INFINITY; idx = 0x7fffffff; }
+        }
+        if (idx < 0) { s = -INFINITY; idx = 0x7fffffff; }
+        s_keys[i] = ((unsigned long long)ord_key(s) << 32) | (0xffffffffu - (uint32_t)idx);
+    }
+    const int k = a.k < n ? a.k : n;  // winners available in this chunk
+    if (tid == 0) { s_prefix = 0ull; s_remaining = k; s_nwin = 0; }
+    __syncthreads();
+
+    if (k > 0 && k < n) {
+        // radix select of the k-th largest key, 8 bits per pass, MSB first
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int byte = 7; byte >= 0; --byte) {
+            s_hist[tid] = 0;
+            __syncthreads();
+            const unsigned long long prefix = s_prefix;
+            const int rem = s_remaining;
+            const int shift = byte * 8;
+            for (int i0 = 0; i0 < n; i0 += SEL_THREADS) {
+                const int i = i0 + tid;
+                bool pending = false;
+                unsigned int d = 0;
+                if (i < n) {
+                    const unsigned long long key = s_keys[i];
+                    pending = (byte == 7) || ((key >> (shift + 8)) == (prefix >> (shift + 8)));
+                    d = (unsigned int)(key >> shift) & 255u;
+                }
+                // wave-aggregate the common case of many lanes sharing a digit (top bytes of
+                // clustered scores), then fall back to one LDS atomic per remaining lane
+#pragma unroll 1
+                for (int it = 0; it < 3; ++it) {
+                    const unsigned long long active = __ballot(pending);
+                    if (!active) break;
+                    const int leader = __ffsll((long long)active) - 1;
+                    const unsigned int ld = __shfl(d, leader);
+                    const unsigned long long same = __ballot(pending && d == ld);
+                    if (lane == leader) atomicAdd(&s_hist[ld], (unsigned int)__popcll(same));
+                    if (d == ld) pending = false;
+                }
+                if (pending) atomicAdd(&s_hist[d], 1u);
+            }
+            __syncthreads();
+            // suffix sums over the 256 bins: thread t owns bin t
+            const unsigned int h = s_hist[tid];
+            unsigned int x = h;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned int y = __shfl_down(x, off);
+                if (lane + off < 64) x += y;
+            }
+            if (lane == 0) s_wsum[wave] = x;
+            __syncthreads();
+            for (int w = wave + 1; w < SEL_THREADS / 64; ++w) x += s_wsum[w];
+            // x = #keys (matching the prefix) with digit >= tid
+            if ((int)x >= rem && (int)(x - h) < rem) {
+                s_prefix = prefix | ((unsigned long long)tid << shift);
+                s_remaining = rem - (int)(x - h);
+            }
+            __syncthreads();
+        }
+    }
+    const unsigned long long kth = (k > 0 && k < n) ? s_prefix : 0ull;
+    // collect winners (key >= kth): exactly k of them
+    for (int i = tid; i < n; i += SEL_THREADS) {
+        const unsigned long long key = s_keys[i];
+        if (k > 0 && key >= kth) {
+            const int p = atomicAdd(&s_nwin, 1);
+            if (p < SEL_MAX_K) s_win[p] = key;
+        }
+    }
+    __syncthreads();
+
+    if (!a.sorted) {
+        // append block (unsorted); pad with (-inf, -1) so every chunk contributes exactly a.k
+        for (int i = tid; i < a.k; i += SEL_THREADS) {
+            float s = -INFINITY;
+            int32_t idx = -1;
+            if (i < k) {
+                const unsigned long long key = s_win[i];
+                idx = (int32_t)(0xffffffffu - (uint32_t)key);
+                if (idx == 0x7fffffff) idx = -1;
+                else s = ord_unkey((uint32_t)(key >> 32));
+            }
+            const int64_t o = (int64_t)q * a.dst_qs + a.dst_off + (int64_t)c * a.k + i;
+            a.dst_scores[o] = s;
+            a.dst_idx[o] = idx;
+        }
+        if (tid == 0) {
+            if (a.cnt_out) atomicAdd(a.cnt_out + q, a.k);
+            if (a.thr_out && k == a.k && k > 0) atomicMax(a.thr_out + q, (uint32_t)(kth >> 32));
+        }
+        return;
+    }
+
+    // sorted output: bitonic sort (descending) of the winners padded to a power of two
+    int P = 1;
+    while (P < a.k) P <<= 1;
+    for (int i = k + tid; i < P; i += SEL_THREADS) s_win[i] = 0ull;
+    __syncthreads();
+    for (int size = 2; size <= P; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < P / 2; t += SEL_THREADS) {
+                const int lo = (t / stride) * stride * 2 + (t % stride);
+                const int hi = lo + stride;
+                const bool desc = ((lo & size) == 0);
+                const unsigned long long x = s_win[lo], y = s_win[hi];
+                if (desc ? (x < y) : (x > y)) { s_win[lo] = y; s_win[hi] = x; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < a.k; i += SEL_THREADS) {
+        float s = -INFINITY;
+        int32_t idx = -1;
+        if (i < k) {
+            const unsigned long long key = s_win[i];
+            idx = (int32_t)(0xffffffffu - (uint32_t)key);
+            if (idx == 0x7fffffff) {
+                idx = -1;  // padding / out-of-range column
+            } else {
+                s = ord_unkey((uint32_t)(key >> 32));
+                idx += a.idx_base;
+            }
+        }
+        a.dst_scores[(int64_t)q * a.dst_qs + i] = s;
+        a.dst_idx[(int64_t)q * a.dst_qs + i] = idx;
+    }
+}
+
+__global__ void fill_u32_kernel(uint32_t* p, uint32_t v, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------
+// Host-side search driver
+// ------------------------------------------------------------------------------------------
+constexpr int QBLOCK = 256;             // queries per pass over the bank
+constexpr int64_t DENSE_COLS = 131072;  // dense score columns kept per query (128 MiB / 256 q)
+constexpr int SEL_CHUNK = 4096;         // dense columns per select workgroup
+constexpr int CAND_CAP_MIN = 8192;      // filter-path candidate slots per query
+
+struct Workspace {
+    float* inv_q;        // [QBLOCK]
+    uint32_t* thr;       // [QBLOCK]
+    int32_t* cnt;        // [QBLOCK]
+    uint32_t* probe;     // [QBLOCK][8]
+    float* cand_scores;  // [qb][cap]
+    int32_t* cand_idx;   // [qb][cap]
+    float* cand2_scores; // [qb][cap2]  (reduce ping-pong)
+    int32_t* cand2_idx;
+    float* dense;        // [qb][dense cols]
+    int cap, cap2;
+    int64_t bytes;
+};
+
+inline int cand_cap(int64_t N, int k) {
+    // the dense path appends k winners per SEL_CHUNK columns; the filter path expects ~1024
+    const int64_t need = ((N + SEL_CHUNK - 1) / SEL_CHUNK + 1) * (int64_t)k;
+    const int64_t cap = need > CAND_CAP_MIN ? need : CAND_CAP_MIN;
+    return (int)align_up(cap, 64);
+}
+
+inline Workspace carve(void* base, int64_t N, int64_t nq, int k) {
+    Workspace w;
+    char* p = static_cast<char*>(base);
+    int64_t off = 0;
+    const int qb = (int)(nq < QBLOCK ? (nq > 0 ? nq : 1) : QBLOCK);
+    auto take = [&](int64_t bytes) {
+        char* r = p ? p + off : nullptr;
+        off += align_up(bytes, 256);
+        return r;
+    };
+    w.cap = cand_cap(N, k);
+    w.cap2 = (int)align_up(((int64_t)w.cap + SEL_LDS_KEYS - 1) / SEL_LDS_KEYS * k, 64);
+    w.inv_q = reinterpret_cast<float*>(take(QBLOCK * 4));
+    w.thr = reinterpret_cast<uint32_t*>(take(QBLOCK * 4));
+    w.cnt = reinterpret_cast<int32_t*>(take(QBLOCK * 4));
+    w.probe = reinterpret_cast<uint32_t*>(take(QBLOCK * 32));
+    w.cand_scores = reinterpret_cast<float*>(take((int64_t)qb * w.cap * 4));
+    w.cand_idx = reinterpret_cast<int32_t*>(take((int64_t)qb * w.cap * 4));
+    w.cand2_scores = reinterpret_cast<float*>(take((int64_t)qb * w.cap2 * 4));
+    w.cand2_idx = reinterpret_cast<int32_t*>(take((int64_t)qb * w.cap2 * 4));
+    const int64_t cols = N < DENSE_COLS ? align_up(N > 0 ? N : 1, 1024) : DENSE_COLS;
+    w.dense = reinterpret_cast<float*>(take((int64_t)qb * cols * 4));
+    w.bytes = off;
+    return w;
+}
+
+inline int launch_select(const SelectArgs& a, int64_t nchunks, int nq, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        // the final select keeps 8192 64-bit keys (64 KiB) + 9 KiB static in LDS
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(topk_select_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                SEL_LDS_KEYS * 8) != hipSuccess)
+            return AURA_E_LAUNCH;
+        attr_set = true;
+    }
+    if (a.chunk > SEL_LDS_KEYS || a.k > SEL_MAX_K) return AURA_E_INVAL;
+    hipLaunchKernelGGL(topk_select_kernel, dim3((unsigned)nchunks, (unsigned)nq), dim3(SEL_THREADS),
+                       (size_t)a.chunk * 8, s, a);
+    return check_launch();
+}
+
+// Optional per-launch timing of the main (FILTER) scan with HIP events on the launch stream:
+// bench.py turns it on to measure the dominant kernel's duration live (aura_profile_*).
+struct ProfileState {
+    hipEvent_t* start = nullptr;
+    hipEvent_t* stop = nullptr;
+    int cap = 0, used = 0;
+    bool on = false;
+};
+ProfileState g_prof;
+
+template <int WQ, int WR, int RT>
+int launch_scan(const ScanArgs& a, int mode, int64_t ntiles_grid, hipStream_t s) {
+    constexpr int BQ = WQ * 32, BR = WR * RT * 32;
+    const size_t lds = (size_t)(BQ + BR) * LDS_STRIDE * sizeof(float);
+    const dim3 grid((unsigned)ntiles_grid, (unsigned)((a.nq + BQ - 1) / BQ));
+    const bool vec4 = (a.D % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.bank) & 15) == 0) &&
+                      ((reinterpret_cast<uintptr_t>(a.queries) & 15) == 0);
+#define AURA_SCAN(MODE, V4)                                                                       \
+    hipLaunchKernelGGL((knn_scan_kernel<WQ, WR, RT, MODE, V4>), grid, dim3(SCAN_THREADS), lds, s, a)
+    if (mode == MODE_DENSE) {
+        if (vec4) AURA_SCAN(MODE_DENSE, true); else AURA_SCAN(MODE_DENSE, false);
+    } else if (mode == MODE_FILTER) {
+        if (vec4) AURA_SCAN(MODE_FILTER, true); else AURA_SCAN(MODE_FILTER, false);
+    } else {
+        if (WQ != 8) return AURA_E_INVAL;  // assign always uses the 256-"query" geometry
+        if (vec4) AURA_SCAN(MODE_ASSIGN, true); else AURA_SCAN(MODE_ASSIGN, false);
+    }
+#undef AURA_SCAN
+    return check_launch();
+}
+
+// bank rows per workgroup tile for a query block of nq
+inline int tile_rows_for(int nq) { return nq <= 64 ? 256 : 128; }
+inline int dispatch_scan(const ScanArgs& a, int mode, int64_t ntiles_grid, hipStream_t s) {
+    if (a.nq <= 32) return launch_scan<1, 8, 1>(a, mode, ntiles_grid, s);   // 32 q x 256 rows
+    if (a.nq <= 64) return launch_scan<2, 4, 2>(a, mode, ntiles_grid, s);   // 64 q x 256 rows
+    if (a.nq <= 128) return launch_scan<4, 2, 2>(a, mode, ntiles_grid, s);  // 128 q x 128 rows
+    return launch_scan<8, 1, 4>(a, mode, ntiles_grid, s);                   // 256 q x 128 rows
+}
+
+}  // namespace
+
+extern "C" {
+
+int aura_bank_row_norms(const float* bank, float* inv_norm, int64_t row0, int64_t n, int64_t D,
+                        void* stream) {
+    if (n < 0 || D <= 0 || row0 < 0) return AURA_E_INVAL;
+    if (n == 0) return AURA_OK;
+    if (!bank || !inv_norm) return AURA_E_INVAL;
+    hipLaunchKernelGGL(row_inv_norm_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), bank + row0 * D, inv_norm + row0, n, D);
+    return check_launch();
+}
+
+int aura_bank_write(float* bank, float* loc, float* meta, float* inv_norm, float* centroids,
+                    float* centroid_counts, int eff_k, const float* feats, const int64_t* slots,
+                    const float* cur_loc, int spatial_dims, float now, int64_t n, int64_t D,
+                    void* stream) {
+    if (n < 0 || D <= 0 || spatial_dims < 0 || spatial_dims > 64) return AURA_E_INVAL;
+    if (n == 0) return AURA_OK;
+    if (!bank || !loc || !meta || !inv_norm || !feats || !slots || !cur_loc) return AURA_E_INVAL;
+    if (reinterpret_cast<uintptr_t>(meta) & 15) return AURA_E_ALIGN;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (centroids) {
+        if (!centroid_counts || eff_k <= 0 || eff_k > 256) return AURA_E_INVAL;
+        hipLaunchKernelGGL(bank_write_centroid_kernel, dim3(1), dim3(1024), 0, s, bank, loc, meta,
+                           inv_norm, centroids, centroid_counts, eff_k, feats, slots, cur_loc,
+                           spatial_dims, now, n, D);
+    } else {
+        hipLaunchKernelGGL(bank_write_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, bank,
+                           loc, meta, inv_norm, feats, slots, cur_loc, spatial_dims, now, -1.0f, n, D);
+    }
+    return check_launch();
+}
+
+int aura_bank_decay(float* meta, float rate, int64_t count, void* stream) {
+    if (count < 0) return AURA_E_INVAL;
+    if (count == 0) return AURA_OK;
+    if (!meta) return AURA_E_INVAL;
+    hipLaunchKernelGGL(bank_decay_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), meta, 1.0f - rate, count);
+    return check_launch();
+}
+
+int aura_bank_gather(const float* bank, const int32_t* idx, float* out, int64_t n, int64_t D,
+                     void* stream) {
+    if (n < 0 || D <= 0) return AURA_E_INVAL;
+    if (n == 0) return AURA_OK;
+    if (!bank || !idx || !out) return AURA_E_INVAL;
+    hipLaunchKernelGGL(bank_gather_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), bank, idx, out, n, D);
+    return check_launch();
+}
+
+int64_t aura_knn_workspace_bytes(int64_t N, int64_t nq, int k) {
+    if (N < 0 || nq < 0 || k <= 0) return AURA_E_INVAL;
+    return carve(nullptr, N, nq, k).bytes;
+}
+
+int aura_knn_search_ex(const float* bank, const float* inv_norm, const float* meta, const float* loc,
+                       int spatial_dims, const float* queries, const float* q_loc, float now,
+                       int64_t N, int64_t D, int64_t nq, int k, int32_t idx_base, float* out_scores,
+                       int32_t* out_idx, void* workspace, int64_t workspace_bytes, int flags,
+                       int32_t* overflow_out, const float* centroids, int nprobe, void* stream) {
+    if (N < 0 || D <= 0 || nq < 0 || k <= 0 || k > SEL_MAX_K || k > N) return AURA_E_INVAL;
+    if (centroids && (nprobe <= 0 || nprobe > 256)) return AURA_E_INVAL;
+    if (flags & ~AURA_KNN_FORCE_DENSE) return AURA_E_INVAL;
+    if (nq == 0) return AURA_OK;
+    if (!bank || !inv_norm || !meta || !queries || !out_scores || !out_idx || !workspace)
+        return AURA_E_INVAL;
+    if (q_loc && (!loc || spatial_dims <= 0 || spatial_dims > 4)) return AURA_E_INVAL;
+    if (N > 0x7ffffff0LL) return AURA_E_INVAL;
+    if (reinterpret_cast<uintptr_t>(meta) & 15) return AURA_E_ALIGN;
+    if (reinterpret_cast<uintptr_t>(workspace) & 255) return AURA_E_ALIGN;
+    const Workspace w = carve(workspace, N, nq, k);
+    if (w.bytes > workspace_bytes) return AURA_E_INVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int rc;
+    if (overflow_out && hipMemsetAsync(overflow_out, 0, 4, s) != hipSuccess) return AURA_E_LAUNCH;
+
+    for (int64_t qb0 = 0; qb0 < nq; qb0 += QBLOCK) {
+        const int nqb = (int)((nq - qb0) < QBLOCK ? (nq - qb0) : QBLOCK);
+        const float* qptr = queries + qb0 * D;
+        const int br = tile_rows_for(nqb);
+        const int64_t ntiles = (N + br - 1) / br;
+
+        hipLaunchKernelGGL(row_inv_norm_kernel, dim3((unsigned)((nqb + 3) / 4)), dim3(256), 0, s,
+                           qptr, w.inv_q, (int64_t)nqb, D);
+        if ((rc = check_launch())) return rc;
+        if (hipMemsetAsync(w.cnt, 0, QBLOCK * 4, s) != hipSuccess) return AURA_E_LAUNCH;
+        if (hipMemsetAsync(w.thr, 0, QBLOCK * 4, s) != hipSuccess) return AURA_E_LAUNCH;
+
+        ScanArgs a{};
+        a.bank = bank; a.inv_norm = inv_norm; a.meta = meta; a.loc = loc;
+        a.queries = qptr; a.inv_q = w.inv_q;
+        a.q_loc = q_loc ? q_loc + qb0 * spatial_dims : nullptr;
+        a.sdims = spatial_dims; a.now = now; a.D = D; a.nq = nqb;
+        a.row_begin = 0; a.row_end = N;
+        a.thr = w.thr; a.cnt = w.cnt; a.cand_scores = w.cand_scores; a.cand_idx = w.cand_idx;
+        a.cap = w.cap;
+        a.dense = w.dense;
+        if (centroids) {
+            hipLaunchKernelGGL(centroid_probe_kernel, dim3((unsigned)nqb), dim3(256), 0, s, centroids,
+                               qptr, D, nprobe, w.probe);
+            if ((rc = check_launch())) return rc;
+            a.probe_mask = w.probe;
+        }
+
+        SelectArgs sel{};   // dense columns -> k winners per SEL_CHUNK appended to the candidates
+        sel.src_scores = w.dense; sel.src_idx = nullptr; sel.src_outer = 0; sel.src_cnt = nullptr;
+        sel.chunk = SEL_CHUNK; sel.blk = br;
+        sel.k = k; sel.sorted = 0;
+        sel.dst_scores = w.cand_scores; sel.dst_idx = w.cand_idx; sel.dst_qs = w.cap;
+        sel.cnt_out = w.cnt; sel.row_end = N;
+
+        // filter path: expected candidates per query ~ k*N/sample_rows; aim for ~1024
+        int64_t sample_rows = (int64_t)k * N / 1024;
+        if (sample_rows < 4096) sample_rows = 4096;
+        const int64_t n_sample_tiles = (sample_rows + br - 1) / br;
+        const bool dense_all = (flags & AURA_KNN_FORCE_DENSE) || n_sample_tiles * 4 > ntiles ||
+                               n_sample_tiles * br > DENSE_COLS;
+        int64_t cur_n;  // candidate slots in use (capacity view) after this stage
+        const int32_t* cur_cnt;
+        if (dense_all) {
+            const int64_t tiles_per_super = DENSE_COLS / br;
+            int64_t appended = 0;
+            for (int64_t t0 = 0; t0 < ntiles; t0 += tiles_per_super) {
+                const int64_t nt = (ntiles - t0) < tiles_per_super ? (ntiles - t0) : tiles_per_super;
+                const int64_t cols = nt * br;
+                a.row_begin = t0 * br; a.tile_step = 1; a.n_sample_tiles = 0; a.dense_ld = cols;
+                if ((rc = dispatch_scan(a, MODE_DENSE, nt, s))) return rc;
+                const int64_t nchunks = (cols + SEL_CHUNK - 1) / SEL_CHUNK;
+                sel.src_qs = cols; sel.src_inner = cols; sel.n_max = cols; sel.step = 1;
+                sel.row_begin = a.row_begin; sel.dst_off = appended * k; sel.thr_out = nullptr;
+                if ((rc = launch_select(sel, nchunks, nqb, s))) return rc;
+                appended += nchunks;
+            }
+            cur_n = appended * k;
+            cur_cnt = nullptr;  // every chunk appended exactly k (padded) entries
+        } else {
+            // 1) strided sample of tiles scored densely -> exact k-th best of the sample per
+            //    query = a valid lower bound of the global k-th best
+            const int tile_step = (int)(ntiles / n_sample_tiles);
+            const int64_t cols = n_sample_tiles * br;
+            a.tile_step = tile_step; a.n_sample_tiles = (int)n_sample_tiles; a.dense_ld = cols;
+            if ((rc = dispatch_scan(a, MODE_DENSE, n_sample_tiles, s))) return rc;
+            const int64_t nchunks = (cols + SEL_CHUNK - 1) / SEL_CHUNK;
+            sel.src_qs = cols; sel.src_inner = cols; sel.n_max = cols; sel.step = tile_step;
+            sel.row_begin = 0; sel.dst_off = 0; sel.thr_out = w.thr;
+            if ((rc = launch_select(sel, nchunks, nqb, s))) return rc;
+            // 2) main scan appends the rows that reach the bound (sample tiles are skipped)
+            const bool prof = g_prof.on && g_prof.used < g_prof.cap;
+            if (prof) (void)hipEventRecord(g_prof.start[g_prof.used], s);
+            if ((rc = dispatch_scan(a, MODE_FILTER, ntiles, s))) return rc;
+            if (prof) (void)hipEventRecord(g_prof.stop[g_prof.used++], s);
+            cur_n = w.cap;
+            cur_cnt = w.cnt;
+        }
+
+        // reduce the candidate lists until they fit one LDS select, then sort the winners
+        const float* cs = w.cand_scores; const int32_t* ci = w.cand_idx; int64_t cqs = w.cap;
+        float* os = w.cand2_scores; int32_t* oi = w.cand2_idx; int64_t oqs = w.cap2;
+        bool first = true;
+        while (cur_n > SEL_LDS_KEYS) {
+            const int64_t nch = (cur_n + SEL_LDS_KEYS - 1) / SEL_LDS_KEYS;
+            SelectArgs r{};
+            r.src_scores = cs; r.src_idx = ci; r.src_qs = cqs; r.src_inner = cqs; r.src_outer = 0;
+            r.src_cnt = cur_cnt; r.n_max = cur_n; r.chunk = SEL_LDS_KEYS; r.blk = 1; r.step = 1;
+            r.row_begin = 0; r.row_end = N; r.k = k; r.sorted = 0;
+            r.dst_scores = os; r.dst_idx = oi; r.dst_qs = oqs; r.dst_off = 0;
+            r.overflow = first ? overflow_out : nullptr;
+            if (nch * k > oqs) return AURA_E_INVAL;
+            if ((rc = launch_select(r, nch, nqb, s))) return rc;
+            // ping-pong
+            const float* ts = cs; const int32_t* ti = ci; const int64_t tq = cqs;
+            cs = os; ci = oi; cqs = oqs;
+            os = const_cast<float*>(ts); oi = const_cast<int32_t*>(ti); oqs = tq;
+            cur_n = nch * k; cur_cnt = nullptr; first = false;
+        }
+        SelectArgs fin{};
+        fin.src_scores = cs; fin.src_idx = ci; fin.src_qs = cqs; fin.src_inner = cqs; fin.src_outer = 0;
+        fin.src_cnt = cur_cnt; fin.n_max = cur_n; fin.chunk = (int)cur_n; fin.blk = 1; fin.step = 1;
+        fin.row_begin = 0; fin.row_end = N; fin.k = k; fin.sorted = 1;
+        fin.dst_scores = out_scores + qb0 * k; fin.dst_idx = out_idx + qb0 * k; fin.dst_qs = k;
+        fin.idx_base = idx_base; fin.overflow = first ? overflow_out : nullptr;
+        if ((rc = launch_select(fin, 1, nqb, s))) return rc;
+    }
+    return AURA_OK;
+}
+
+int aura_knn_search(const float* bank, const float* inv_norm, const float* meta, const float* loc,
+                    int spatial_dims, const float* queries, const float* q_loc, float now,
+                    int64_t N, int64_t D, int64_t nq, int k, int32_t idx_base, float* out_scores,
+                    int32_t* out_idx, void* workspace, int64_t workspace_bytes, void* stream) {
+    return aura_knn_search_ex(bank, inv_norm, meta, loc, spatial_dims, queries, q_loc, now, N, D, nq,
+                              k, idx_base, out_scores, out_idx, workspace, workspace_bytes, 0,
+                              nullptr, nullptr, 0, stream);
+}
+
+int aura_topk_merge(const float* in_scores, const int32_t* in_idx, int S, int64_t nq, int k,
+                    float* out_scores, int32_t* out_idx, void* stream) {
+    if (S <= 0 || nq < 0 || k <= 0 || k > SEL_MAX_K) return AURA_E_INVAL;
+    if (nq == 0) return AURA_OK;
+    if (!in_scores || !in_idx || !out_scores || !out_idx) return AURA_E_INVAL;
+    if ((int64_t)S * k > SEL_LDS_KEYS) return AURA_E_INVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    for (int64_t q0 = 0; q0 < nq; q0 += 32768) {
+        const int64_t nb = (nq - q0) < 32768 ? (nq - q0) : 32768;
+        SelectArgs m{};
+        m.src_scores = in_scores + q0 * k; m.src_idx = in_idx + q0 * k;
+        m.src_qs = k; m.src_inner = k; m.src_outer = nq * k;
+        m.src_cnt = nullptr; m.n_max = (int64_t)S * k; m.chunk = S * k;
+        m.blk = 1; m.step = 1; m.row_begin = 0; m.row_end = 0x7fffffff;
+        m.k = k; m.sorted = 1; m.dst_scores = out_scores + q0 * k; m.dst_idx = out_idx + q0 * k;
+        m.dst_qs = k; m.idx_base = 0;
+        int rc = launch_select(m, 1, (int)nb, s);
+        if (rc) return rc;
+    }
+    return AURA_OK;
+}
+
+int aura_kmeans_assign(const float* bank, const float* centroids, float* cnorm2_ws,
+                       int32_t* assign_out, int64_t N, int64_t D, int k, void* stream) {
+    if (N < 0 || D <= 0 || k <= 0 || k > 256) return AURA_E_INVAL;
+    if (N == 0) return AURA_OK;
+    if (!bank || !centroids || !cnorm2_ws || !assign_out) return AURA_E_INVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(row_norm2_kernel, dim3((unsigned)((k + 3) / 4)), dim3(256), 0, s, centroids,
+                       cnorm2_ws, (int64_t)k, D);
+    int rc = check_launch();
+    if (rc) return rc;
+    ScanArgs a{};
+    a.bank = bank; a.queries = centroids; a.D = D; a.nq = k;
+    a.row_begin = 0; a.row_end = N; a.tile_step = 1;
+    a.qnorm2 = cnorm2_ws; a.assign_out = assign_out;
+    return launch_scan<8, 1, 4>(a, MODE_ASSIGN, (N + 127) / 128, s);
+}
+
+int aura_kmeans_update(const float* bank, const int32_t* assign, float* centroids, float* counts,
+                       float* meta, int64_t N, int64_t D, int k, int update_means, void* stream) {
+    if (N < 0 || D <= 0 || k <= 0 || k > 256) return AURA_E_INVAL;
+    if (!bank || !assign || !centroids) return AURA_E_INVAL;
+    const size_t lds = (size_t)4 * D * sizeof(float);
+    if (lds > 150 * 1024) return AURA_E_INVAL;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kmeans_update_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+            return AURA_E_LAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kmeans_update_kernel, dim3((unsigned)k), dim3(256), lds,
+                       static_cast<hipStream_t>(stream), bank, assign, centroids, counts, meta, N, D,
+                       update_means);
+    return check_launch();
+}
+
+int aura_profile_begin(int max_launches) {
+    if (max_launches <= 0 || max_launches > 65536) return AURA_E_INVAL;
+    if (g_prof.cap < max_launches) {
+        for (int i = 0; i < g_prof.cap; ++i) { (void)hipEventDestroy(g_prof.start[i]); (void)hipEventDestroy(g_prof.stop[i]); }
+        delete[] g_prof.start; delete[] g_prof.stop;
+        g_prof.start = new hipEvent_t[max_launches];
+        g_prof.stop = new hipEvent_t[max_launches];
+        for (int i = 0; i < max_launches; ++i) {
+            if (hipEventCreate(&g_prof.start[i]) != hipSuccess || hipEventCreate(&g_prof.stop[i]) != hipSuccess)
+                return AURA_E_LAUNCH;
+        }
+        g_prof.cap = max_launches;
+    }
+    g_prof.used = 0;
+    g_prof.on = true;
+    return AURA_OK;
+}
+
+int aura_profile_end(float* ms_out_host, int max_out) {
+    g_prof.on = false;
+    if (!ms_out_host || max_out < 0) return AURA_E_INVAL;
+    int n = g_prof.used < max_out ? g_prof.used : max_out;
+    for (int i = 0; i < n; ++i) {
+        if (hipEventSynchronize(g_prof.stop[i]) != hipSuccess) return AURA_E_LAUNCH;
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, g_prof.start[i], g_prof.stop[i]) != hipSuccess) return AURA_E_LAUNCH;
+        ms_out_host[i] = ms;
+    }
+    return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,508 @@
+// aura_neuron.hip -- fused membrane-update loops for gfx950 (MI355X, wave64).
+//
+// One launch runs the WHOLE T loop of a neuron population with the state (v,u / V,w / mem /
+// v,theta) held in registers, so HBM sees each input current once and each output spike once:
+//   Izhikevich / AdEx fp32 : 4 B in + 4 B out + 16/T B state per neuron-timestep
+//   LIF single step fp32   : 16 B;   GIF fp32: 8 B + 16/T;   GIF bf16: 4 B + 8/T
+// (SURVEY.md section 8d).  All of these kernels are HBM-bandwidth bound; there is no matrix work
+// here, so no MFMA.  Two data layouts exist in the reference:
+//   * time-contiguous   I[N][T]    (IzhikevichNeuron / AdExNeuron 1-D/2-D inputs) -- a lane owns a
+//     neuron but HBM wants lanes along t, so each wave transposes 64x32 tiles through LDS;
+//   * channel-contiguous x[R][T][C] (3-D inputs, LIF, GIF) -- a lane owns VEC adjacent channels
+//     and streams 16-byte vectors down the T axis, fully coalesced with no LDS.
+//
+// Arithmetic contract: every expression is evaluated in the reference's op order in IEEE fp32
+// with NO fused multiply-add (the reference runs unfused eager PyTorch ops and floor()/>= turn a
+// 1-ulp difference into a spike).  The file is compiled with -ffp-contract=off and repeats the
+// pragma below; division and exp are the correctly rounded / OCML forms.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/aura_hip.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// Neuron models.  Lane = per-neuron registers (state s0,s1 + per-channel constants).
+// ------------------------------------------------------------------------------------------
+
+// src/base/neuron.py:186-195
+struct IzhModel {
+    float a, b, c, d, dt;
+    static constexpr int NS = 2;
+    struct Lane { float s0, s1; };
+    __device__ __forceinline__ void init(Lane&, int64_t) const {}
+    __device__ __forceinline__ float step(Lane& l, float i_t) const {
+        float v = l.s0, u = l.s1;
+        float dv = 0.04f * v * v + 5.0f * v + 140.0f - u + i_t;
+        v = v + dt * dv;
+        float du = a * (b * v - u);
+        u = u + dt * du;
+        bool spk = v >= 30.0f;
+        l.s0 = spk ? c : v;
+        l.s1 = spk ? u + d : u;
+        return spk ? 1.0f : 0.0f;
+    }
+};
+
+// src/base/neuron.py:237-247
+struct AdExModel {
+    float tau_m, E_L, V_T, Delta_T, R, tau_w, a, b, V_reset, V_spike, dt;
+    static constexpr int NS = 2;
+    struct Lane { float s0, s1; };
+    __device__ __forceinline__ void init(Lane&, int64_t) const {}
+    __device__ __forceinline__ float step(Lane& l, float i_t) const {
+        float V = l.s0, w = l.s1;
+        float exp_term = Delta_T * expf((V - V_T) / Delta_T);
+        float dV = (-(V - E_L) + exp_term - R * w + R * i_t) / tau_m;
+        V = V + dt * dV;
+        float dw = (a * (V - E_L) - w) / tau_w;
+        w = w + dt * dw;
+        bool spk = V >= V_spike;
+        l.s0 = spk ? V_reset : V;
+        l.s1 = spk ? w + b : w;
+        return spk ? 1.0f : 0.0f;
+    }
+};
+
+// src/base/neuron.py:135-137 (forward value of the surrogate, :77)
+struct LifModel {
+    const float* beta;
+    const float* thr;
+    static constexpr int NS = 1;
+    struct Lane { float s0, s1, beta, thr; };
+    __device__ __forceinline__ void init(Lane& l, int64_t c) const {
+        l.beta = beta[c];
+        l.thr = thr[c];
+    }
+    __device__ __forceinline__ float step(Lane& l, float x) const {
+        float mem = l.beta * l.s0 + x;
+        float spk = (mem - l.thr) > 0.0f ? 1.0f : 0.0f;
+        l.s0 = mem - spk * l.thr;
+        return spk;
+    }
+};
+
+__device__ __forceinline__ float round_bf16(float x) {
+    // round-to-nearest-even through the hardware convert (v_cvt_pk_bf16_f32); NaN stays NaN
+    return static_cast<float>(static_cast<__bf16>(x));
+}
+
+// src/core/language_zone/gif_neuron.py:56-67.  BF16 = state and every intermediate are bf16
+// tensors in the reference, i.e. each op rounds its fp32 result to bf16.
+template <bool BF16>
+struct GifModel {
+    float decay, Lf, alpha, thr0;
+    static constexpr int NS = 2;
+    struct Lane { float s0, s1; };
+    __device__ __forceinline__ static float r(float x) { return BF16 ? round_bf16(x) : x; }
+    __device__ __forceinline__ void init(Lane&, int64_t) const {}
+    __device__ __forceinline__ float step(Lane& l, float i_t) const {
+        float v = l.s0, theta = l.s1;
+        v = r(r(v * decay) + i_t);
+        float cl = r(r(Lf * theta) * 2.0f);
+        v = fminf(fmaxf(v, -cl), cl);
+        float nv = r(v / r(theta + 1e-6f));
+        float spike = fminf(fmaxf(floorf(nv), 0.0f), Lf);
+        v = r(v - r(spike * theta));
+        if (alpha > 0.0f) theta = r(r(theta + r(alpha * spike)) - r(alpha * r(theta - thr0)));
+        l.s0 = v;
+        l.s1 = theta;
+        return spike;
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// 16-byte vector I/O
+// ------------------------------------------------------------------------------------------
+template <typename T, int VEC>
+struct Io;
+
+template <>
+struct Io<float, 4> {
+    __device__ __forceinline__ static void load(const float* p, float (&x)[4]) {
+        float4 t = *reinterpret_cast<const float4*>(p);
+        x[0] = t.x; x[1] = t.y; x[2] = t.z; x[3] = t.w;
+    }
+    __device__ __forceinline__ static void store(float* p, const float (&x)[4]) {
+        *reinterpret_cast<float4*>(p) = make_float4(x[0], x[1], x[2], x[3]);
+    }
+};
+template <>
+struct Io<float, 1> {
+    __device__ __forceinline__ static void load(const float* p, float (&x)[1]) { x[0] = *p; }
+    __device__ __forceinline__ static void store(float* p, const float (&x)[1]) { *p = x[0]; }
+};
+
+__device__ __forceinline__ float bf16_bits_to_float(uint32_t b) { return __uint_as_float(b << 16); }
+__device__ __forceinline__ uint32_t float_to_bf16_bits(float x) {
+    return __float_as_uint(round_bf16(x)) >> 16;
+}
+
+template <>
+struct Io<uint16_t, 8> {
+    __device__ __forceinline__ static void load(const uint16_t* p, float (&x)[8]) {
+        uint4 t = *reinterpret_cast<const uint4*>(p);
+        uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            x[2 * i] = __uint_as_float(w[i] << 16);
+            x[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+        }
+    }
+    __device__ __forceinline__ static void store(uint16_t* p, const float (&x)[8]) {
+        uint32_t w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            w[i] = float_to_bf16_bits(x[2 * i]) | (float_to_bf16_bits(x[2 * i + 1]) << 16);
+        *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+};
+template <>
+struct Io<uint16_t, 1> {
+    __device__ __forceinline__ static void load(const uint16_t* p, float (&x)[1]) {
+        x[0] = bf16_bits_to_float(*p);
+    }
+    __device__ __forceinline__ static void store(uint16_t* p, const float (&x)[1]) {
+        *p = static_cast<uint16_t>(float_to_bf16_bits(x[0]));
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// Channel-contiguous kernel: x[R][T][C] (or [R][C] if TIME_INV) -> out[R][T][C] (or the T-mean
+// [R][C] if MEAN_OUT); state st0/st1 [R][C].  One work item = VEC adjacent channels of one row.
+// ------------------------------------------------------------------------------------------
+constexpr int RTC_UNROLL = 4;
+
+template <class Model, typename T, int VEC, bool TIME_INV, bool MEAN_OUT, bool BF16_MEAN>
+__global__ __launch_bounds__(256) void seq_rtc_kernel(Model m, const T* __restrict__ x,
+                                                      T* __restrict__ out, T* st0, T* st1,
+                                                      int64_t R, int64_t Tn, int64_t C) {
+    const int64_t cvecs = C / VEC;
+    const int64_t items = R * cvecs;
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < items;
+         it += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = it / cvecs;
+        const int64_t c0 = (it - row * cvecs) * VEC;
+        typename Model::Lane lane[VEC];
+        float s0[VEC], s1[VEC];
+        Io<T, VEC>::load(st0 + row * C + c0, s0);
+        if (Model::NS > 1) Io<T, VEC>::load(st1 + row * C + c0, s1);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            m.init(lane[e], c0 + e);
+            lane[e].s0 = s0[e];
+            if (Model::NS > 1) lane[e].s1 = s1[e];
+        }
+        float acc[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] = 0.0f;
+
+        const T* xp = x + (TIME_INV ? row * C + c0 : row * Tn * C + c0);
+        T* op = out + (MEAN_OUT ? row * C + c0 : row * Tn * C + c0);
+
+        if (TIME_INV) {
+            float xin[VEC], spk[VEC];
+            Io<T, VEC>::load(xp, xin);
+            for (int64_t t = 0; t < Tn; ++t) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    spk[e] = m.step(lane[e], xin[e]);
+                    acc[e] += spk[e];
+                }
+                if (!MEAN_OUT) Io<T, VEC>::store(op + t * C, spk);
+            }
+        } else {
+            int64_t t = 0;
+            for (; t + RTC_UNROLL <= Tn; t += RTC_UNROLL) {
+                float xin[RTC_UNROLL][VEC];
+#pragma unroll
+                for (int j = 0; j < RTC_UNROLL; ++j) Io<T, VEC>::load(xp + (t + j) * C, xin[j]);
+#pragma unroll
+                for (int j = 0; j < RTC_UNROLL; ++j) {
+                    float spk[VEC];
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        spk[e] = m.step(lane[e], xin[j][e]);
+                        acc[e] += spk[e];
+                    }
+                    if (!MEAN_OUT) Io<T, VEC>::store(op + (t + j) * C, spk);
+                }
+            }
+            for (; t < Tn; ++t) {
+                float xin[VEC], spk[VEC];
+                Io<T, VEC>::load(xp + t * C, xin);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    spk[e] = m.step(lane[e], xin[e]);
+                    acc[e] += spk[e];
+                }
+                if (!MEAN_OUT) Io<T, VEC>::store(op + t * C, spk);
+            }
+        }
+        if (MEAN_OUT) {
+            // spikes.mean(dim=1): sum (exact: small integers) then a true division by T
+            // (snn_ffn.py:81); in bf16 the sum is rounded to bf16 before the division.
+            float mean[VEC];
+            const float tf = static_cast<float>(Tn);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) mean[e] = (BF16_MEAN ? round_bf16(acc[e]) : acc[e]) / tf;
+            Io<T, VEC>::store(op, mean);
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            s0[e] = lane[e].s0;
+            if (Model::NS > 1) s1[e] = lane[e].s1;
+        }
+        Io<T, VEC>::store(st0 + row * C + c0, s0);
+        if (Model::NS > 1) Io<T, VEC>::store(st1 + row * C + c0, s1);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Time-contiguous kernel: I[N][T] -> S[N][T]; lane owns neuron (wave*64 + lane).  Each wave
+// moves 64 neurons x 32 timesteps through a private LDS tile: HBM side is read/written with
+// lanes along t (8 lanes x 16 B per 128-byte row segment), the compute side reads its own row
+// as 8 x ds_read_b128.  Row stride 36 floats (144 B) keeps both the 16-byte row-segment writes
+// and the per-lane ds_read_b128 of 64 different rows bank-conflict-free (slot = 9*row mod 16 is
+// a permutation on each ds_read_b128 lane group) and 16-byte aligned.
+// The next chunk's loads are issued before the current chunk is computed (register prefetch).
+// ------------------------------------------------------------------------------------------
+constexpr int NT_TC = 32;      // timesteps per chunk
+constexpr int NT_STRIDE = 36;  // floats per LDS row
+constexpr int NT_WAVES = 4;
+
+template <class Model, int VEC>
+__global__ __launch_bounds__(64 * NT_WAVES) void seq_nt_kernel(Model m, const float* __restrict__ I,
+                                                               float* __restrict__ S, float* st0,
+                                                               float* st1, int64_t N, int64_t Tn) {
+    constexpr int LPR = NT_TC / VEC;  // lanes per row
+    constexpr int RPI = 64 / LPR;     // rows per wave-instruction
+    constexpr int NI = 64 / RPI;      // wave-instructions per tile
+    __shared__ __attribute__((aligned(16))) float tiles[NT_WAVES][64 * NT_STRIDE];
+
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    float* tile = tiles[wave];
+    const int64_t n0 = ((int64_t)blockIdx.x * NT_WAVES + wave) * 64;
+    const int64_t n = n0 + lane;
+    const int lrow = lane / LPR;
+    const int lcol = (lane % LPR) * VEC;
+
+    typename Model::Lane ln;
+    m.init(ln, n);
+    ln.s0 = 0.0f;
+    ln.s1 = 0.0f;
+    if (n < N) {
+        ln.s0 = st0[n];
+        if (Model::NS > 1) ln.s1 = st1[n];
+    }
+
+    float reg[NI][VEC];
+    auto load_chunk = [&](int64_t c0) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int64_t rn = n0 + i * RPI + lrow;
+            const int64_t t = c0 + lcol;
+            if (rn < N && t < Tn) {
+                Io<float, VEC>::load(I + rn * Tn + t, reg[i]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) reg[i][e] = 0.0f;
+            }
+        }
+    };
+
+    load_chunk(0);
+    for (int64_t c0 = 0; c0 < Tn; c0 += NT_TC) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            Io<float, VEC>::store(tile + (i * RPI + lrow) * NT_STRIDE + lcol, reg[i]);
+        if (c0 + NT_TC < Tn) load_chunk(c0 + NT_TC);
+        __syncthreads();
+
+        const int tc = (Tn - c0) < NT_TC ? (int)(Tn - c0) : NT_TC;
+        float* myrow = tile + lane * NT_STRIDE;
+#pragma unroll
+        for (int j = 0; j < NT_TC / 4; ++j) {
+            if (4 * j < tc) {
+                float xin[4], spk[4];
+                Io<float, 4>::load(myrow + 4 * j, xin);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    spk[e] = 0.0f;
+                    if (4 * j + e < tc) spk[e] = m.step(ln, xin[e]);
+                }
+                Io<float, 4>::store(myrow + 4 * j, spk);
+            }
+        }
+        __syncthreads();
+
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int64_t rn = n0 + i * RPI + lrow;
+            const int64_t t = c0 + lcol;
+            if (rn < N && t < Tn) {
+                float o[VEC];
+                Io<float, VEC>::load(tile + (i * RPI + lrow) * NT_STRIDE + lcol, o);
+                Io<float, VEC>::store(S + rn * Tn + t, o);
+            }
+        }
+        __syncthreads();
+    }
+    if (n < N) {
+        st0[n] = ln.s0;
+        if (Model::NS > 1) st1[n] = ln.s1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Host-side launch helpers
+// ------------------------------------------------------------------------------------------
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+inline int check_launch() {
+    return hipGetLastError() == hipSuccess ? AURA_OK : AURA_E_LAUNCH;
+}
+
+inline int rtc_grid(int64_t items) {
+    // memory-bound streaming: cap at 256 CUs x 8 blocks and grid-stride the rest
+    int64_t blocks = (items + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+template <class Model>
+int launch_nt(const Model& m, const float* I, float* S, float* st0, float* st1, int64_t N,
+              int64_t T, hipStream_t s) {
+    if (N == 0 || T == 0) return AURA_OK;
+    const int64_t blocks = (N + 64 * NT_WAVES - 1) / (64 * NT_WAVES);
+    if (blocks > 0x7fffffffLL) return AURA_E_INVAL;
+    const bool vec = (T % 4 == 0) && aligned16(I) && aligned16(S);
+    if (vec)
+        hipLaunchKernelGGL((seq_nt_kernel<Model, 4>), dim3((unsigned)blocks), dim3(64 * NT_WAVES),
+                           0, s, m, I, S, st0, st1, N, T);
+    else
+        hipLaunchKernelGGL((seq_nt_kernel<Model, 1>), dim3((unsigned)blocks), dim3(64 * NT_WAVES),
+                           0, s, m, I, S, st0, st1, N, T);
+    return check_launch();
+}
+
+template <class Model>
+int launch_rtc_f32(const Model& m, const float* x, float* out, float* st0, float* st1, int64_t R,
+                   int64_t T, int64_t C, hipStream_t s) {
+    if (R == 0 || C == 0) return AURA_OK;
+    const bool vec = (C % 4 == 0) && aligned16(x) && aligned16(out) && aligned16(st0) &&
+                     (Model::NS == 1 || aligned16(st1));
+    if (vec)
+        hipLaunchKernelGGL((seq_rtc_kernel<Model, float, 4, false, false, false>),
+                           dim3(rtc_grid(R * (C / 4))), dim3(256), 0, s, m, x, out, st0, st1, R, T,
+                           C);
+    else
+        hipLaunchKernelGGL((seq_rtc_kernel<Model, float, 1, false, false, false>),
+                           dim3(rtc_grid(R * C)), dim3(256), 0, s, m, x, out, st0, st1, R, T, C);
+    return check_launch();
+}
+
+template <typename T, int VEC, bool BF16>
+int launch_gif(const GifModel<BF16>& m, const void* h, void* out, void* v, void* th, int64_t rows,
+               int64_t Tn, int64_t H, int flags, hipStream_t s) {
+    const T* hp = static_cast<const T*>(h);
+    T* op = static_cast<T*>(out);
+    T* vp = static_cast<T*>(v);
+    T* tp = static_cast<T*>(th);
+    const dim3 g(rtc_grid(rows * (H / VEC))), b(256);
+    const bool ti = flags & AURA_GIF_TIME_INVARIANT, mo = flags & AURA_GIF_MEAN_OUT;
+#define AURA_GIF_LAUNCH(TI, MO)                                                                  \
+    hipLaunchKernelGGL((seq_rtc_kernel<GifModel<BF16>, T, VEC, TI, MO, BF16>), g, b, 0, s, m, hp, \
+                       op, vp, tp, rows, Tn, H)
+    if (ti && mo) AURA_GIF_LAUNCH(true, true);
+    else if (ti) AURA_GIF_LAUNCH(true, false);
+    else if (mo) AURA_GIF_LAUNCH(false, true);
+    else AURA_GIF_LAUNCH(false, false);
+#undef AURA_GIF_LAUNCH
+    return check_launch();
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* aura_version(void) { return "aura_hip 0.1.0 gfx950"; }
+
+int aura_izh_run_nt(const float* I, float* spikes, float* v, float* u, float a, float b, float c,
+                    float d, float dt, int64_t N, int64_t T, void* stream) {
+    if (N < 0 || T < 0) return AURA_E_INVAL;
+    if (N && T && (!I || !spikes)) return AURA_E_INVAL;
+    if (N && (!v || !u)) return AURA_E_INVAL;
+    IzhModel m{a, b, c, d, dt};
+    return launch_nt(m, I, spikes, v, u, N, T, static_cast<hipStream_t>(stream));
+}
+
+int aura_izh_run_btd(const float* I, float* spikes, float* v, float* u, float a, float b, float c,
+                     float d, float dt, int64_t B, int64_t T, int64_t D, void* stream) {
+    if (B < 0 || T < 0 || D < 0) return AURA_E_INVAL;
+    if (B && D && (!v || !u || (T && (!I || !spikes)))) return AURA_E_INVAL;
+    IzhModel m{a, b, c, d, dt};
+    return launch_rtc_f32(m, I, spikes, v, u, B, T, D, static_cast<hipStream_t>(stream));
+}
+
+static AdExModel adex_from(const float* p) {
+    return AdExModel{p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8], p[9], p[10]};
+}
+
+int aura_adex_run_nt(const float* I, float* spikes, float* V, float* w, const float* params_host,
+                     int64_t N, int64_t T, void* stream) {
+    if (N < 0 || T < 0 || !params_host) return AURA_E_INVAL;
+    if (N && (!V || !w || (T && (!I || !spikes)))) return AURA_E_INVAL;
+    return launch_nt(adex_from(params_host), I, spikes, V, w, N, T,
+                     static_cast<hipStream_t>(stream));
+}
+
+int aura_adex_run_btd(const float* I, float* spikes, float* V, float* w, const float* params_host,
+                      int64_t B, int64_t T, int64_t D, void* stream) {
+    if (B < 0 || T < 0 || D < 0 || !params_host) return AURA_E_INVAL;
+    if (B && D && (!V || !w || (T && (!I || !spikes)))) return AURA_E_INVAL;
+    return launch_rtc_f32(adex_from(params_host), I, spikes, V, w, B, T, D,
+                          static_cast<hipStream_t>(stream));
+}
+
+int aura_lif_run(const float* x, float* spikes, float* mem, const float* beta,
+                 const float* threshold, int64_t B, int64_t T, int64_t size, void* stream) {
+    if (B < 0 || T < 0 || size < 0) return AURA_E_INVAL;
+    if (B && size && (!mem || !beta || !threshold || (T && (!x || !spikes)))) return AURA_E_INVAL;
+    LifModel m{beta, threshold};
+    return launch_rtc_f32(m, x, spikes, mem, static_cast<float*>(nullptr), B, T, size,
+                          static_cast<hipStream_t>(stream));
+}
+
+int aura_gif_run(const void* h, void* out, void* v, void* theta, float decay, int L, float alpha,
+                 float threshold, int64_t rows, int64_t T, int64_t H, int dtype, int flags,
+                 void* stream) {
+    if (rows < 0 || T < 0 || H < 0 || L < 0) return AURA_E_INVAL;
+    if (dtype != AURA_DTYPE_F32 && dtype != AURA_DTYPE_BF16) return AURA_E_INVAL;
+    if (flags & ~(AURA_GIF_TIME_INVARIANT | AURA_GIF_MEAN_OUT)) return AURA_E_INVAL;
+    if (rows == 0 || H == 0) return AURA_OK;
+    if (!v || !theta || (T && (!h || !out))) return AURA_E_INVAL;
+    if ((flags & AURA_GIF_MEAN_OUT) && T == 0) return AURA_E_INVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool al = aligned16(h) && aligned16(out) && aligned16(v) && aligned16(theta);
+    if (dtype == AURA_DTYPE_F32) {
+        GifModel<false> m{decay, (float)L, alpha, threshold};
+        if (al && H % 4 == 0) return launch_gif<float, 4, false>(m, h, out, v, theta, rows, T, H, flags, s);
+        return launch_gif<float, 1, false>(m, h, out, v, theta, rows, T, H, flags, s);
+    }
+    // bf16 scalars: the reference multiplies bf16 tensors by Python floats in fp32 opmath
+    // (the scalar is NOT rounded to bf16 first), so decay/alpha/threshold stay fp32 here.
+    GifModel<true> m{decay, (float)L, alpha, threshold};
+    if (al && H % 8 == 0) return launch_gif<uint16_t, 8, true>(m, h, out, v, theta, rows, T, H, flags, s);
+    return launch_gif<uint16_t, 1, true>(m, h, out, v, theta, rows, T, H, flags, s);
+}
+
+}  // extern "C"

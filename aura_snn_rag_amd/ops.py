@@ -1,0 +1,321 @@
+"""Tensor-level wrappers over the C ABI (``include/aura_hip.h``).
+
+Every function takes HIP-resident, contiguous torch tensors, checks shapes/dtypes on the host
+(a bad shape reaching a hand-written kernel can fault the GPU) and launches on torch's current
+stream.  There is no fallback: CPU tensors raise ``AuraDeviceError``.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import check
+
+
+class AuraDeviceError(RuntimeError):
+    """Raised when a hot-path op is asked to run on something that is not a HIP device."""
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need(t: torch.Tensor, name: str, dtype=None) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor, got {type(t)}")
+    if not t.is_cuda:
+        raise AuraDeviceError(
+            f"{name} is on {t.device}: aura_snn_rag_amd runs the hot path only as HIP kernels on "
+            f"an AMD GPU (no CPU/PyTorch fallback).")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    return t
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def lib():
+    return _lib.load()
+
+
+# ---------------------------------------------------------------------------------------
+# neurons
+# ---------------------------------------------------------------------------------------
+
+def izh_run_nt(I, spikes, v, u, a, b, c, d, dt) -> None:
+    """I, spikes: [N, T] fp32; v, u: [N] fp32 (updated in place)."""
+    _need(I, "I", torch.float32); _need(spikes, "spikes", torch.float32)
+    _need(v, "v", torch.float32); _need(u, "u", torch.float32)
+    N, T = I.shape
+    if spikes.shape != I.shape or v.numel() != N or u.numel() != N:
+        raise ValueError("izh_run_nt: shape mismatch")
+    check(lib().aura_izh_run_nt(_p(I), _p(spikes), _p(v), _p(u), a, b, c, d, dt, N, T, _stream()),
+          "aura_izh_run_nt")
+
+
+def izh_run_btd(I, spikes, v, u, a, b, c, d, dt) -> None:
+    """I, spikes: [B, T, D] fp32; v, u: [B*D] fp32 indexed b*D+d."""
+    _need(I, "I", torch.float32); _need(spikes, "spikes", torch.float32)
+    _need(v, "v", torch.float32); _need(u, "u", torch.float32)
+    B, T, D = I.shape
+    if spikes.shape != I.shape or v.numel() != B * D or u.numel() != B * D:
+        raise ValueError("izh_run_btd: shape mismatch")
+    check(lib().aura_izh_run_btd(_p(I), _p(spikes), _p(v), _p(u), a, b, c, d, dt, B, T, D,
+                                 _stream()), "aura_izh_run_btd")
+
+
+def _adex_params(params: Sequence[float]):
+    if len(params) != 11:
+        raise ValueError("AdEx needs 11 parameters")
+    return (ctypes.c_float * 11)(*[float(x) for x in params])
+
+
+def adex_run_nt(I, spikes, V, w, params: Sequence[float]) -> None:
+    _need(I, "I", torch.float32); _need(spikes, "spikes", torch.float32)
+    _need(V, "V", torch.float32); _need(w, "w", torch.float32)
+    N, T = I.shape
+    if spikes.shape != I.shape or V.numel() != N or w.numel() != N:
+        raise ValueError("adex_run_nt: shape mismatch")
+    arr = _adex_params(params)
+    check(lib().aura_adex_run_nt(_p(I), _p(spikes), _p(V), _p(w), ctypes.addressof(arr), N, T,
+                                 _stream()), "aura_adex_run_nt")
+
+
+def adex_run_btd(I, spikes, V, w, params: Sequence[float]) -> None:
+    _need(I, "I", torch.float32); _need(spikes, "spikes", torch.float32)
+    _need(V, "V", torch.float32); _need(w, "w", torch.float32)
+    B, T, D = I.shape
+    if spikes.shape != I.shape or V.numel() != B * D or w.numel() != B * D:
+        raise ValueError("adex_run_btd: shape mismatch")
+    arr = _adex_params(params)
+    check(lib().aura_adex_run_btd(_p(I), _p(spikes), _p(V), _p(w), ctypes.addressof(arr), B, T, D,
+                                  _stream()), "aura_adex_run_btd")
+
+
+def lif_run(x, spikes, mem, beta, threshold) -> None:
+    """x, spikes: [B, T, size]; mem: [B, size] in/out; beta, threshold: [size]."""
+    for t, n in ((x, "x"), (spikes, "spikes"), (mem, "mem"), (beta, "beta"), (threshold, "threshold")):
+        _need(t, n, torch.float32)
+    B, T, size = x.shape
+    if spikes.shape != x.shape or mem.shape != (B, size) or beta.numel() != size or \
+            threshold.numel() != size:
+        raise ValueError("lif_run: shape mismatch")
+    check(lib().aura_lif_run(_p(x), _p(spikes), _p(mem), _p(beta), _p(threshold), B, T, size,
+                             _stream()), "aura_lif_run")
+
+
+def gif_run(h, out, v, theta, decay: float, L: int, alpha: float, threshold: float, T: int,
+            time_invariant: bool = False, mean_out: bool = False) -> None:
+    """h: [rows, T, H] (or [rows, H] if time_invariant); out: [rows, T, H] (or [rows, H] if
+    mean_out); v, theta: [rows, H] in/out.  fp32 or bf16 (all four the same dtype)."""
+    dt = h.dtype
+    if dt not in (torch.float32, torch.bfloat16):
+        raise TypeError(f"gif_run supports fp32 and bf16, got {dt}")
+    for t, n in ((h, "h"), (out, "out"), (v, "v"), (theta, "theta")):
+        _need(t, n, dt)
+    rows, H = v.shape
+    if theta.shape != v.shape:
+        raise ValueError("gif_run: v/theta shape mismatch")
+    if tuple(h.shape) != ((rows, H) if time_invariant else (rows, T, H)):
+        raise ValueError(f"gif_run: h has shape {tuple(h.shape)}")
+    if tuple(out.shape) != ((rows, H) if mean_out else (rows, T, H)):
+        raise ValueError(f"gif_run: out has shape {tuple(out.shape)}")
+    flags = (_lib.GIF_TIME_INVARIANT if time_invariant else 0) | (_lib.GIF_MEAN_OUT if mean_out else 0)
+    check(lib().aura_gif_run(_p(h), _p(out), _p(v), _p(theta), decay, int(L), alpha, threshold,
+                             rows, T, H, _lib.DTYPE_F32 if dt == torch.float32 else _lib.DTYPE_BF16,
+                             flags, _stream()), "aura_gif_run")
+
+
+# ---------------------------------------------------------------------------------------
+# episodic bank
+# ---------------------------------------------------------------------------------------
+
+def bank_row_norms(bank, inv_norm, row0: int, n: int) -> None:
+    _need(bank, "bank", torch.float32); _need(inv_norm, "inv_norm", torch.float32)
+    M, D = bank.shape
+    if row0 < 0 or n < 0 or row0 + n > M or inv_norm.numel() != M:
+        raise ValueError("bank_row_norms: range out of bounds")
+    check(lib().aura_bank_row_norms(_p(bank), _p(inv_norm), row0, n, D, _stream()),
+          "aura_bank_row_norms")
+
+
+def bank_write(bank, loc, meta, inv_norm, feats, slots, cur_loc, now: float,
+               centroids=None, centroid_counts=None, eff_k: int = 0) -> None:
+    """Write feats[n, D] into rows ``slots`` (int64 [n], device)."""
+    for t, n_ in ((bank, "bank"), (loc, "loc"), (meta, "meta"), (inv_norm, "inv_norm"),
+                  (feats, "feats"), (cur_loc, "cur_loc")):
+        _need(t, n_, torch.float32)
+    _need(slots, "slots", torch.int64)
+    M, D = bank.shape
+    n = feats.shape[0]
+    sd = loc.shape[1]
+    if feats.shape != (n, D) or slots.numel() != n or meta.shape != (M, 4) or \
+            loc.shape[0] != M or cur_loc.numel() != sd or inv_norm.numel() != M:
+        raise ValueError("bank_write: shape mismatch")
+    if n and (int(slots.min()) < 0 or int(slots.max()) >= M):
+        raise ValueError("bank_write: slot out of range")
+    if centroids is not None:
+        _need(centroids, "centroids", torch.float32)
+        _need(centroid_counts, "centroid_counts", torch.float32)
+        if centroids.shape[1] != D or not (0 < eff_k <= centroids.shape[0] <= 256) or \
+                centroid_counts.numel() < eff_k:
+            raise ValueError("bank_write: centroid shape mismatch")
+    check(lib().aura_bank_write(_p(bank), _p(loc), _p(meta), _p(inv_norm), _p(centroids),
+                                _p(centroid_counts), eff_k, _p(feats), _p(slots), _p(cur_loc), sd,
+                                now, n, D, _stream()), "aura_bank_write")
+
+
+def bank_decay(meta, rate: float, count: int) -> None:
+    _need(meta, "meta", torch.float32)
+    if count < 0 or count > meta.shape[0] or meta.shape[1] != 4:
+        raise ValueError("bank_decay: bad count")
+    check(lib().aura_bank_decay(_p(meta), rate, count, _stream()), "aura_bank_decay")
+
+
+_workspaces = {}
+
+
+def _workspace(device, nbytes: int) -> torch.Tensor:
+    ws = _workspaces.get(device)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
+        _workspaces[device] = ws
+    return ws
+
+
+def knn_search(bank, inv_norm, meta, queries, k: int, now: float, count: Optional[int] = None,
+               loc=None, q_loc=None, idx_base: int = 0, force_dense: bool = False,
+               centroids=None, nprobe: int = 0, check_overflow: bool = True
+               ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Exact batched recall over rows [0, count) -> (scores [nq, k] fp32, idx [nq, k] int32).
+
+    ``centroids`` (256 x D) + ``nprobe`` switches on the reference's centroid-candidate
+    selection.  ``check_overflow`` reads one int back (a host sync) and transparently re-runs the
+    dense path if a candidate list overflowed; pass False inside latency-critical loops whose
+    data is known to be well behaved.
+    """
+    _need(bank, "bank", torch.float32); _need(inv_norm, "inv_norm", torch.float32)
+    _need(meta, "meta", torch.float32); _need(queries, "queries", torch.float32)
+    M, D = bank.shape
+    N = M if count is None else int(count)
+    nq = queries.shape[0]
+    if queries.dim() != 2 or queries.shape[1] != D:
+        raise ValueError(f"knn_search: queries must be [nq, {D}]")
+    if not (0 < N <= M) or meta.shape != (M, 4) or inv_norm.numel() != M:
+        raise ValueError("knn_search: bad bank/count")
+    if not (0 < k <= min(N, 1024)):
+        raise ValueError(f"knn_search: k={k} must be in [1, min(N, 1024)]")
+    sd = 0
+    if q_loc is not None:
+        _need(loc, "loc", torch.float32); _need(q_loc, "q_loc", torch.float32)
+        sd = loc.shape[1]
+        if q_loc.shape != (nq, sd) or loc.shape[0] != M or sd > 4:
+            raise ValueError("knn_search: location shape mismatch")
+    if centroids is not None:
+        _need(centroids, "centroids", torch.float32)
+        if centroids.shape != (256, D) or not (0 < nprobe <= 256):
+            raise ValueError("knn_search: centroids must be [256, D]")
+    dev = bank.device
+    out_s = torch.empty(nq, k, dtype=torch.float32, device=dev)
+    out_i = torch.empty(nq, k, dtype=torch.int32, device=dev)
+    if nq == 0:
+        return out_s, out_i
+    L = lib()
+    nbytes = L.aura_knn_workspace_bytes(N, nq, k)
+    if nbytes < 0:
+        raise _lib.AuraHipError("aura_knn_workspace_bytes failed")
+    ws = _workspace(dev, nbytes)
+    base = (ws.data_ptr() + 255) // 256 * 256
+    ovf = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def run(flags):
+        check(L.aura_knn_search_ex(_p(bank), _p(inv_norm), _p(meta), _p(loc), sd, _p(queries),
+                                   _p(q_loc), now, N, D, nq, k, idx_base, _p(out_s), _p(out_i),
+                                   base, nbytes, flags, _p(ovf), _p(centroids), nprobe, _stream()),
+              "aura_knn_search_ex")
+
+    run(_lib.KNN_FORCE_DENSE if force_dense else 0)
+    if check_overflow and not force_dense and int(ovf.item()) != 0:
+        run(_lib.KNN_FORCE_DENSE)
+    return out_s, out_i
+
+
+def topk_merge(scores, idx, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """scores, idx: [S, nq, k] per-shard lists -> merged (scores [nq, k], idx [nq, k])."""
+    _need(scores, "scores", torch.float32); _need(idx, "idx", torch.int32)
+    S, nq, kk = scores.shape
+    if idx.shape != scores.shape or kk != k:
+        raise ValueError("topk_merge: shape mismatch")
+    out_s = torch.empty(nq, k, dtype=torch.float32, device=scores.device)
+    out_i = torch.empty(nq, k, dtype=torch.int32, device=scores.device)
+    check(lib().aura_topk_merge(_p(scores), _p(idx), S, nq, k, _p(out_s), _p(out_i), _stream()),
+          "aura_topk_merge")
+    return out_s, out_i
+
+
+def bank_gather(bank, idx) -> torch.Tensor:
+    """rows of ``bank`` at int32 ``idx`` (any shape); -1 -> zeros."""
+    _need(bank, "bank", torch.float32); _need(idx, "idx", torch.int32)
+    D = bank.shape[1]
+    n = idx.numel()
+    if n and int(idx.max()) >= bank.shape[0]:
+        raise ValueError("bank_gather: index out of range")
+    out = torch.empty(*idx.shape, D, dtype=torch.float32, device=bank.device)
+    check(lib().aura_bank_gather(_p(bank), _p(idx), _p(out), n, D, _stream()), "aura_bank_gather")
+    return out
+
+
+def kmeans_assign(bank, centroids, count: int, k: int) -> torch.Tensor:
+    """Nearest of the first k centroids for rows [0, count) -> int32 [count]."""
+    _need(bank, "bank", torch.float32); _need(centroids, "centroids", torch.float32)
+    M, D = bank.shape
+    if not (0 <= count <= M) or centroids.shape[1] != D or not (0 < k <= min(256, centroids.shape[0])):
+        raise ValueError("kmeans_assign: shape mismatch")
+    assign = torch.empty(count, dtype=torch.int32, device=bank.device)
+    ws = torch.empty(256, dtype=torch.float32, device=bank.device)
+    check(lib().aura_kmeans_assign(_p(bank), _p(centroids), _p(ws), _p(assign), count, D, k,
+                                   _stream()), "aura_kmeans_assign")
+    return assign
+
+
+def kmeans_update(bank, assign, centroids, k: int, counts=None, meta=None,
+                  update_means: bool = True) -> None:
+    _need(bank, "bank", torch.float32); _need(assign, "assign", torch.int32)
+    _need(centroids, "centroids", torch.float32)
+    N = assign.numel()
+    D = bank.shape[1]
+    if N > bank.shape[0] or centroids.shape[1] != D or not (0 < k <= min(256, centroids.shape[0])):
+        raise ValueError("kmeans_update: shape mismatch")
+    if counts is not None:
+        _need(counts, "counts", torch.float32)
+        if counts.numel() < k:
+            raise ValueError("kmeans_update: counts too small")
+    if meta is not None:
+        _need(meta, "meta", torch.float32)
+        if meta.shape[0] < N or meta.shape[1] != 4:
+            raise ValueError("kmeans_update: meta shape mismatch")
+    check(lib().aura_kmeans_update(_p(bank), _p(assign), _p(centroids), _p(counts), _p(meta), N, D,
+                                   k, 1 if update_means else 0, _stream()), "aura_kmeans_update")
+
+
+def addition_linear(x, weight_patterns, bias=None) -> torch.Tensor:
+    """-||w_o - x_b||_1 (+ bias): x [B, in], weight_patterns [out, in] -> [B, out]."""
+    _need(x, "x", torch.float32); _need(weight_patterns, "weight_patterns", torch.float32)
+    if x.dim() != 2 or weight_patterns.dim() != 2 or x.shape[1] != weight_patterns.shape[1]:
+        raise ValueError("addition_linear: x must be [B, in] and weights [out, in]")
+    if bias is not None:
+        _need(bias, "bias", torch.float32)
+        if bias.numel() != weight_patterns.shape[0]:
+            raise ValueError("addition_linear: bias shape mismatch")
+    out = torch.empty(x.shape[0], weight_patterns.shape[0], dtype=torch.float32, device=x.device)
+    check(lib().aura_addition_linear(_p(x), _p(weight_patterns), _p(bias), _p(out), x.shape[0],
+                                     x.shape[1], weight_patterns.shape[0], _stream()),
+          "aura_addition_linear")
+    return out

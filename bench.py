@@ -1,0 +1,261 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the hot path on MI355X.
+
+Metric (BASELINE.json): retrievals/s of the episodic cosine-kNN.  One "step" = one 256-query
+batch per rank recalled against the whole bank (top-32), inputs resident in HBM.
+
+  N = 1  : BASELINE config 2 -- 100 000 x 768 fp32 bank, 256-query batch, top-32.
+  N > 1  : the same bank row-sharded over N ranks (100 000 / N rows each); every rank brings its
+           own 256-query batch; a step = all-gather the queries (RCCL), scan the local shard for
+           all N*256 queries, all-gather the per-shard top-k, merge.  Per-GPU scan work is
+           constant in N ("weak"): value = N*256*steps / time.  --bank-rows 1000000 gives the
+           1 M-row bank of config 4.
+
+Also reported on the same JSON line: `roofline` of the dominant kernel (main MFMA scan, timed
+with HIP events on its launch stream via aura_profile_*), `cpu_baseline` (the oracle's
+reference-cost recall on the host cores, rank 0, N = 1 only) and `secondary` (neuron-timestep
+throughput of the fused Izhikevich / GIF loops with their HBM roofline fractions).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+MFMA_F32_PEAK_TF = 157.3    # fp32 matrix peak (v_mfma_f32_32x32x2_f32), dense
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--bank-rows", type=int, default=100_000)
+    ap.add_argument("--dim", type=int, default=768)
+    ap.add_argument("--nq", type=int, default=256)
+    ap.add_argument("--k", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--cpu-queries", type=int, default=32)
+    return ap.parse_args()
+
+
+def make_shard(rows, dim, seed, dev):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    # generate in chunks to bound host memory
+    out = torch.empty(rows, dim, device=dev)
+    step = 65536
+    for r0 in range(0, rows, step):
+        n = min(step, rows - r0)
+        out[r0:r0 + n] = torch.randn(n, dim, generator=g).to(dev)
+    return out
+
+
+def secondary_neurons(dev):
+    """Fused neuron-loop throughput: Izhikevich 2^22 x 100 (time-contiguous layout) and the GIF
+    loop of one SNNFFN layer at config 3 (512 x 16 x 3072 bf16)."""
+    from aura_snn_rag_amd import ops
+    res = {}
+
+    def timed(fn, iters=10):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        st = [torch.cuda.Event(enable_timing=True) for _ in range(iters)]
+        en = [torch.cuda.Event(enable_timing=True) for _ in range(iters)]
+        for i in range(iters):
+            st[i].record(); fn(); en[i].record()
+        torch.cuda.synchronize()
+        ms = sorted(s.elapsed_time(e) for s, e in zip(st, en))
+        return ms[len(ms) // 2]
+
+    N, T = 1 << 22, 100
+    I = 20 * torch.rand(N, T, device=dev)
+    S = torch.empty_like(I)
+    v = torch.full((N,), -65.0, device=dev); u = 0.2 * v
+    ms = timed(lambda: ops.izh_run_nt(I, S, v, u, 0.02, 0.2, -65.0, 8.0, 0.2))
+    bytes_alg = N * T * 8 + N * 16
+    res["izhikevich_nt"] = {"neurons": N, "timesteps": T, "dtype": "f32",
+                            "neuron_timesteps_per_s": N * T / (ms * 1e-3),
+                            "ms": ms, "algorithmic_bytes": bytes_alg,
+                            "hbm_gbs": bytes_alg / (ms * 1e-3) / 1e9,
+                            "hbm_frac_of_8TBs": bytes_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    del I, S, v, u
+    B, T2, D = 4096, 100, 1024
+    I = 20 * torch.rand(B, T2, D, device=dev); S = torch.empty_like(I)
+    v = torch.full((B * D,), -65.0, device=dev); u = 0.2 * v
+    ms = timed(lambda: ops.izh_run_btd(I, S, v, u, 0.02, 0.2, -65.0, 8.0, 0.2))
+    bytes_alg = B * D * T2 * 8 + B * D * 16
+    res["izhikevich_btd"] = {"neurons": B * D, "timesteps": T2, "dtype": "f32",
+                             "neuron_timesteps_per_s": B * D * T2 / (ms * 1e-3), "ms": ms,
+                             "algorithmic_bytes": bytes_alg,
+                             "hbm_gbs": bytes_alg / (ms * 1e-3) / 1e9,
+                             "hbm_frac_of_8TBs": bytes_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    del I, S, v, u
+    # GIF at config 3, interface traffic: h in + spikes out + state, bf16; many rows to fill HBM
+    rows, T3, H = 8192, 16, 3072
+    h = (torch.randn(rows, T3, H, device=dev) * 2).to(torch.bfloat16)
+    out = torch.empty_like(h)
+    vv = torch.zeros(rows, H, device=dev, dtype=torch.bfloat16); th = torch.ones_like(vv)
+    import math
+    ms = timed(lambda: ops.gif_run(h, out, vv, th, math.exp(-0.1), 8, 0.01, 1.0, T3))
+    bytes_alg = rows * T3 * H * 4 + rows * H * 8
+    res["gif_bf16"] = {"rows": rows, "timesteps": T3, "hidden": H, "dtype": "bf16",
+                       "neuron_timesteps_per_s": rows * T3 * H / (ms * 1e-3), "ms": ms,
+                       "algorithmic_bytes": bytes_alg,
+                       "hbm_gbs": bytes_alg / (ms * 1e-3) / 1e9,
+                       "hbm_frac_of_8TBs": bytes_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    return res
+
+
+def cpu_baseline(bank_rows, dim, k, nq_sample):
+    """The oracle's recall at the REFERENCE's cost model (bank re-normalised per query,
+    hippocampal.py:273-279) on the host cores; bit-identical to the reference (tests)."""
+    from oracle import aura_oracle as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    g = torch.Generator().manual_seed(1234)
+    ob = O.OracleBank(bank_rows, dim, use_centroid_index=False)
+    ob.features = torch.randn(bank_rows, dim, generator=g)
+    ob.metadata[:, 0] = 1.0
+    now = 1.7e9
+    ob.metadata[:, 1] = now
+    ob.count = bank_rows
+    q = torch.randn(nq_sample, dim, generator=g)
+    ob.recall(q[0], k, now)  # warm-up
+    t0 = time.perf_counter()
+    for i in range(nq_sample):
+        ob.recall(q[i], k, now)
+    dt = time.perf_counter() - t0
+    return {"value": nq_sample / dt, "unit": "retrievals/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"{nq_sample} single-query recalls (reference algorithm: per-query bank "
+                      f"normalise + mm + topk) over the same {bank_rows}x{dim} fp32 bank, k={k}"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from aura_snn_rag_amd import _lib, ops
+    from aura_snn_rag_amd.sharded import ShardedRecall, shard_rows
+    lib = _lib.load()
+
+    D, k, nq = args.dim, args.k, args.nq
+    r0, r1 = shard_rows(args.bank_rows, world, rank)
+    rows = r1 - r0
+    bank = make_shard(rows, D, 1234 + rank, dev)
+    inv = torch.empty(rows, device=dev)
+    ops.bank_row_norms(bank, inv, 0, rows)
+    now = 1.7e9
+    meta = torch.zeros(rows, 4, device=dev)
+    meta[:, 0] = 1.0; meta[:, 1] = now; meta[:, 2] = -1
+    g = torch.Generator(device="cpu").manual_seed(99 + rank)
+    pick = torch.randint(0, rows, (nq // 2,), generator=g)
+    q = torch.cat([bank[pick.to(dev)] + 0.05 * torch.randn(nq // 2, D, generator=g).to(dev),
+                   torch.randn(nq - nq // 2, D, generator=g).to(dev)]).contiguous()
+
+    def local_search(qq, kk, check=False):
+        return ops.knn_search(bank, inv, meta, qq, kk, now, count=rows, idx_base=r0, check_overflow=check)
+
+    recall = ShardedRecall(local_search, ops.topk_merge)
+
+    def step(check=False):
+        if world == 1:
+            return local_search(q, k, check)
+        return recall.recall(q, k, all_gather_queries=True)
+
+    # correctness guard before timing: overflow check + planted neighbours found
+    s, i = step(check=True) if world == 1 else step()
+    torch.cuda.synchronize()
+    planted_ok = bool((i[: nq // 2, 0].cpu() == (pick + r0).to(torch.int32)).float().mean() > 0.99)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    lib.aura_profile_begin(max(1, args.steps * 4))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    buf = (ctypes.c_float * (args.steps * 4))()
+    nprof = lib.aura_profile_end(buf, args.steps * 4)
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    total_q = nq * world * args.steps
+    value = total_q / elapsed
+    # dominant kernel: main MFMA scan; algorithmic FLOP per launch = 2 * nq_scanned * rows_scanned * D
+    nq_scan = nq * world
+    qblocks = (nq_scan + 255) // 256
+    kernel_ms = sorted(buf[j] for j in range(nprof))
+    roof = None
+    if nprof > 0:
+        avg_ms = sum(kernel_ms) / nprof
+        br = 256 if min(nq_scan, 256) <= 64 else 128
+        sample_rows = max(4096, k * rows // 1024)
+        n_sample_tiles = -(-sample_rows // br)
+        ntiles = -(-rows // br)
+        dense_all = n_sample_tiles * 4 > ntiles
+        scanned_rows = rows - (0 if dense_all else n_sample_tiles * br)
+        flop = 2.0 * min(nq_scan, 256) * scanned_rows * D
+        tf = flop / (avg_ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "knn_scan_kernel<8,1,4,FILTER> (v_mfma_f32_32x32x2_f32)",
+                "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF,
+                "traffic": None, "avg_kernel_ms": avg_ms, "launches_timed": nprof,
+                "algorithmic_flop_per_launch": flop,
+                "algorithmic_bytes_per_launch": scanned_rows * D * 4 + scanned_rows * 24 + min(nq_scan, 256) * D * 4,
+                "hbm_gbs_at_kernel": (scanned_rows * D * 4) / (avg_ms * 1e-3) / 1e9,
+                "launches_per_step": nprof / args.steps}
+
+    out = {
+        "metric": "retrievals/sec", "value": value, "unit": "retrievals/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"episodic cosine-kNN recall: {args.bank_rows}x{D} fp32 bank "
+                               f"({'row-sharded over %d ranks' % world if world > 1 else 'one GPU'}), "
+                               f"{nq}-query batch per rank, top-{k}, exact fp32 scores",
+                   "bank_rows": args.bank_rows, "dim": D, "queries_per_rank": nq, "k": k,
+                   "parallelism": f"bank-sharded x{world}" if world > 1 else "single"},
+        "planted_neighbours_found": planted_ok,
+        "roofline": roof,
+    }
+    if rank == 0 and world == 1 and not args.no_secondary:
+        out["secondary"] = secondary_neurons(dev)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.bank_rows, D, k, args.cpu_queries)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,186 @@
+/*
+ * aura_hip.h -- C ABI of libaura_hip.so: the MI355X (gfx950) implementation of Aura's
+ * SNN-timestep + episodic-retrieval hot path.
+ *
+ * The reference (auralmn/aura-snn-rag) is 100 % Python/PyTorch and has no FFI of its own
+ * (SURVEY.md section 0); the boundary it exposes for this path is the nn.Module API listed in
+ * SURVEY.md section 8b.  Each entry point below names the reference method whose arithmetic it
+ * replaces (file:line relative to the upstream checkout).  The Python classes in
+ * aura_snn_rag_amd/ keep the reference's signatures and call these through ctypes
+ * (INTEGRATION.md shows the binding a reference maintainer would add).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless it says "host";
+ *   - sizes are element counts, int64_t; tensors are dense row-major;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); every call is
+ *     asynchronous on that stream and never synchronises or allocates;
+ *   - the return value is 0 on success, a negative AURA_E_* code otherwise; nothing throws;
+ *   - all arithmetic is IEEE fp32 without FMA contraction in the neuron loops, so results are
+ *     bit-identical to the reference's unfused PyTorch op sequence.
+ */
+#ifndef AURA_HIP_H
+#define AURA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AURA_OK 0
+#define AURA_E_INVAL (-1)   /* bad argument (null pointer, negative size, unsupported value) */
+#define AURA_E_LAUNCH (-2)  /* HIP reported a launch error */
+#define AURA_E_ALIGN (-3)   /* pointer alignment requirement violated */
+
+#define AURA_DTYPE_F32 0
+#define AURA_DTYPE_BF16 1
+
+/* gif flags */
+#define AURA_GIF_TIME_INVARIANT 1 /* h is [rows, H]: the same current at every timestep */
+#define AURA_GIF_MEAN_OUT 2       /* out is [rows, H] = mean over T of the spikes */
+
+/* Library identification: returns a static string "aura_hip <version> gfx950". */
+const char* aura_version(void);
+
+/* ---------------------------------------------------------------------------------------
+ * Spiking-neuron membrane loops
+ * ------------------------------------------------------------------------------------- */
+
+/* Izhikevich Euler loop, time-contiguous layout I[N][T] -> spikes[N][T]; v,u [N] in/out.
+ * Replaces IzhikevichNeuron._jit_step_loop, src/base/neuron.py:181-196 (2-D / 1-D inputs of
+ * forward_sequence, :162-167). */
+int aura_izh_run_nt(const float* I, float* spikes, float* v, float* u, float a, float b, float c,
+                    float d, float dt, int64_t N, int64_t T, void* stream);
+
+/* Same loop, channel-contiguous layout I[B][T][D] -> spikes[B][T][D]; state index b*D+d.
+ * Replaces the 3-D branch of forward_sequence (permute/reshape, src/base/neuron.py:158-160,
+ * 176-178) without materialising the permuted copy. */
+int aura_izh_run_btd(const float* I, float* spikes, float* v, float* u, float a, float b, float c,
+                     float d, float dt, int64_t B, int64_t T, int64_t D, void* stream);
+
+/* AdEx Euler loop; params = the 11-float buffer of src/base/neuron.py:207
+ * {tau_m,E_L,V_T,Delta_T,R,tau_w,a,b,V_reset,V_spike,dt} passed BY VALUE from the host.
+ * Replaces AdExNeuron._jit_step_loop, src/base/neuron.py:233-248. */
+int aura_adex_run_nt(const float* I, float* spikes, float* V, float* w, const float* params_host,
+                     int64_t N, int64_t T, void* stream);
+int aura_adex_run_btd(const float* I, float* spikes, float* V, float* w, const float* params_host,
+                      int64_t B, int64_t T, int64_t D, void* stream);
+
+/* Vectorised LIF over x[B][T][size] (T = 1 is the single step of VectorizedLIFNeuron.forward,
+ * src/base/neuron.py:131-139; T > 1 is the per-t loop of EnhancedSpikingNeuron.forward,
+ * src/base/snn_brain_zones.py:73-79).  beta, threshold: [size]; mem: [B][size] in/out. */
+int aura_lif_run(const float* x, float* spikes, float* mem, const float* beta,
+                 const float* threshold, int64_t B, int64_t T, int64_t size, void* stream);
+
+/* GIF membrane loop (decay, clamp, divide, floor-spike, soft reset, threshold adaptation).
+ * h: currents after the neuron's nn.Linear, [rows][T][H] (or [rows][H] with
+ * AURA_GIF_TIME_INVARIANT); out: spikes [rows][T][H] (or the T-mean [rows][H] with
+ * AURA_GIF_MEAN_OUT); v, theta: [rows][H] in/out; dtype of h/out/v/theta = AURA_DTYPE_*.
+ * In bf16 every op rounds to bf16, as the reference does (state dtype follows the input,
+ * gif_neuron.py:46-47).  Replaces GIFNeuron.forward's loop,
+ * src/core/language_zone/gif_neuron.py:54-69 (+ MultiBitSurrogate.forward :11-13) and the
+ * spikes.mean(dim=1) readout of SNNFFN.forward, snn_ffn.py:81. */
+int aura_gif_run(const void* h, void* out, void* v, void* theta, float decay, int L, float alpha,
+                 float threshold, int64_t rows, int64_t T, int64_t H, int dtype, int flags,
+                 void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Episodic bank (HippocampalFormation)
+ * ------------------------------------------------------------------------------------- */
+
+/* inv_norm[i] = 1 / max(||bank[row0+i]||_2, 1e-12) for i in [0, n): the per-row factor of
+ * F.normalize(active_feats, dim=1), src/core/hippocampal.py:278, hoisted out of the query. */
+int aura_bank_row_norms(const float* bank, float* inv_norm, int64_t row0, int64_t n, int64_t D,
+                        void* stream);
+
+/* One-shot write of n rows: bank[slots[i]] = feats[i]; loc[slots[i]] = cur_loc;
+ * meta[slots[i]] = {1, now, cid, 0}; inv_norm[slots[i]] refreshed.  With centroids != NULL
+ * each row is assigned to its nearest centroid among the first `eff_k` (L2), the centroid's
+ * running mean and count are updated IN ROW ORDER (c <- (1-1/n)c + (1/n)x), and cid is stored;
+ * otherwise cid = -1.  slots: int64 [n] device.  Replaces create_episodic_memory's tensor
+ * work, src/core/hippocampal.py:211-232. */
+int aura_bank_write(float* bank, float* loc, float* meta, float* inv_norm, float* centroids,
+                    float* centroid_counts, int eff_k, const float* feats, const int64_t* slots,
+                    const float* cur_loc, int spatial_dims, float now, int64_t n, int64_t D,
+                    void* stream);
+
+/* meta[i][0] *= (1 - rate) for i < count.  Replaces decay_memories, hippocampal.py:334. */
+int aura_bank_decay(float* meta, float rate, int64_t count, void* stream);
+
+/* Workspace size (bytes) aura_knn_search needs for (N, nq, k). */
+int64_t aura_knn_workspace_bytes(int64_t N, int64_t nq, int k);
+
+/* Exact batched recall: for each of nq queries the top-k rows of bank[0..N) by the reference's
+ * combined score (0.5*cos + 0.3*spatial + 0.2*exp(-(now-ts)/3600)) * strength, descending,
+ * ties -> lower row index.  q_loc == NULL means "no location" (spatial = 0).
+ * Outputs: out_scores [nq][k] fp32, out_idx [nq][k] int32 (row index + idx_base).
+ * k <= min(N, 1024).  workspace: aura_knn_workspace_bytes(N, nq, k) bytes of HBM.
+ * Replaces retrieve_similar_memories steps 1-5, src/core/hippocampal.py:272-307, for a batch
+ * of queries (the reference is called once per batch row,
+ * memory_augmented_layer.py:113-121). */
+int aura_knn_search(const float* bank, const float* inv_norm, const float* meta, const float* loc,
+                    int spatial_dims, const float* queries, const float* q_loc, float now,
+                    int64_t N, int64_t D, int64_t nq, int k, int32_t idx_base, float* out_scores,
+                    int32_t* out_idx, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* As aura_knn_search with extras: centroids != NULL restricts each query's candidates to the rows
+ * whose centroid id (meta[.][2]) is among the `nprobe` nearest (L2, unnormalised query) of the
+ * 256 centroid rows -- the candidate selection of retrieve_similar_memories,
+ * src/core/hippocampal.py:259-270 (a query left without candidates returns idx -1 everywhere and
+ * the caller falls back to the full scan, :269-270); flags (AURA_KNN_FORCE_DENSE scores every row densely instead
+ * of using the sampled-threshold filter; same results, used by tests) and overflow_out (device
+ * int32, set to 1 if a candidate list overflowed -- the caller must then re-run with
+ * AURA_KNN_FORCE_DENSE; may be NULL). */
+#define AURA_KNN_FORCE_DENSE 1
+int aura_knn_search_ex(const float* bank, const float* inv_norm, const float* meta,
+                       const float* loc, int spatial_dims, const float* queries,
+                       const float* q_loc, float now, int64_t N, int64_t D, int64_t nq, int k,
+                       int32_t idx_base, float* out_scores, int32_t* out_idx, void* workspace,
+                       int64_t workspace_bytes, int flags, int32_t* overflow_out,
+                       const float* centroids, int nprobe, void* stream);
+
+/* Measurement hooks (bench.py): between aura_profile_begin(max) and aura_profile_end, every
+ * launch of the main scan kernel inside aura_knn_search[_ex] is bracketed by HIP events recorded
+ * on the launch stream.  aura_profile_end synchronises those events, writes up to max_out
+ * per-launch durations in milliseconds to the HOST array and returns how many it wrote
+ * (negative AURA_E_* on error). */
+int aura_profile_begin(int max_launches);
+int aura_profile_end(float* ms_out_host, int max_out);
+
+/* Merge S per-shard top-k lists into the global top-k (the step after the RCCL all-gather,
+ * SURVEY.md section 8e).  in_scores/in_idx: [S][nq][k]; out: [nq][k]; ties -> lower index. */
+int aura_topk_merge(const float* in_scores, const int32_t* in_idx, int S, int64_t nq, int k,
+                    float* out_scores, int32_t* out_idx, void* stream);
+
+/* k-means-lite pieces of rebuild_centroids, src/core/hippocampal.py:358-376.
+ * assign: assign_out[i] = argmin_c ||bank[i] - centroids[c]|| over the first k centroids
+ *   (computed as argmin |c|^2 - 2 x.c on the fp32 matrix cores; ties -> lower c);
+ *   cnorm2_ws: k floats of scratch.
+ * update: for each c < k, count = #{i: assign[i]==c}; if update_means and count > 0,
+ *   centroids[c] = mean of those rows (empty clusters keep their centroid, :362-363);
+ *   counts[c] = count (if counts != NULL); meta[i][2] = assign[i] (if meta != NULL). */
+int aura_kmeans_assign(const float* bank, const float* centroids, float* cnorm2_ws,
+                       int32_t* assign_out, int64_t N, int64_t D, int k, void* stream);
+int aura_kmeans_update(const float* bank, const int32_t* assign, float* centroids, float* counts,
+                       float* meta, int64_t N, int64_t D, int k, int update_means, void* stream);
+
+/* Gather rows: out[i] = bank[idx[i]] (idx < 0 -> zeros); used to return [B,k,D] memory features
+ * (memory_augmented_layer.py:124-128). */
+int aura_bank_gather(const float* bank, const int32_t* idx, float* out, int64_t n, int64_t D,
+                     void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Brain-zone projection
+ * ------------------------------------------------------------------------------------- */
+
+/* out[b][o] = -sum_k |x[b][k] - weight_patterns[o][k]| (+ bias[o] if bias != NULL).
+ * Replaces AdditionLinear.forward, src/maths/addition_linear.py:42-67, the in/out projection of
+ * NeuromorphicBrainZone.forward (src/base/snn_brain_zones.py:139,161). */
+int aura_addition_linear(const float* x, const float* weight_patterns, const float* bias,
+                         float* out, int64_t B, int64_t in_features, int64_t out_features,
+                         void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AURA_HIP_H */

@@ -1,0 +1,265 @@
+"""GPU parity: episodic-bank kernels (write, scan + top-k, centroid candidates, k-means, merge)
+vs the CPU oracle.  Rows must be exact except at fp32 near-ties (helpers.topk_equivalent);
+scores within 1e-5."""
+import pytest
+import torch
+
+from oracle import aura_oracle as O
+from tests.helpers import topk_equivalent
+
+pytestmark = pytest.mark.gpu
+NOW = 1.7e9 + 12345.678
+
+
+def _bank(N, D, seed=1234, scale=True):
+    g = torch.Generator().manual_seed(seed)
+    bank = torch.randn(N, D, generator=g)
+    if scale:
+        bank = bank * (0.5 + 1.5 * torch.rand(N, 1, generator=g))
+    return bank, g
+
+
+def _meta(N, g, decayed=False, spread_ts=False):
+    meta = torch.zeros(N, 4)
+    meta[:, 0] = 0.5 + 0.5 * torch.rand(N, generator=g) if decayed else 1.0
+    meta[:, 1] = NOW - (torch.rand(N, generator=g) * 7200.0 if spread_ts else 0.0)
+    meta[:, 2] = -1
+    return meta
+
+
+def _queries(bank, nq, g):
+    half = nq // 2
+    pick = torch.randint(0, bank.shape[0], (half,), generator=g)
+    q1 = bank[pick] + 0.05 * torch.randn(half, bank.shape[1], generator=g)
+    q2 = torch.randn(nq - half, bank.shape[1], generator=g)
+    return torch.cat([q1, q2], dim=0)
+
+
+def _search(dev, bank, meta, q, k, **kw):
+    from aura_snn_rag_amd import ops
+    b = bank.to(dev).contiguous()
+    inv = torch.empty(b.shape[0], device=dev)
+    ops.bank_row_norms(b, inv, 0, b.shape[0])
+    return ops.knn_search(b, inv, meta.to(dev).contiguous(), q.to(dev).contiguous(), k, NOW, **kw)
+
+
+@pytest.mark.parametrize("N,D,nq,k", [
+    (600, 32, 8, 10), (5000, 64, 1, 5), (5000, 64, 7, 1), (5000, 64, 33, 32), (5000, 64, 100, 32),
+    (5000, 64, 256, 32), (3000, 48, 300, 5), (20000, 128, 64, 32), (257, 4, 5, 5), (129, 768, 3, 129),
+    (70000, 64, 16, 32), (70000, 64, 256, 8),
+])
+def test_exact_search_matches_oracle(dev, N, D, nq, k):
+    bank, g = _bank(N, D, seed=N + D)
+    meta = _meta(N, g, decayed=True, spread_ts=True)
+    q = _queries(bank, nq, g)
+    ri, rs = O.knn_exact_batch(bank, meta[:, 0], meta[:, 1], q, k, NOW)
+    for force in (True, False):
+        s, i = _search(dev, bank, meta, q, k, force_dense=force)
+        exact, n, ok = topk_equivalent(i, s, ri, rs)
+        assert ok, f"force_dense={force}: mismatch beyond near-tie tolerance"
+        assert exact >= n - max(1, n // 50), f"only {exact}/{n} queries index-exact"
+    # dense and filter paths must agree bit for bit with each other
+    s1, i1 = _search(dev, bank, meta, q, k, force_dense=True)
+    s2, i2 = _search(dev, bank, meta, q, k, force_dense=False)
+    assert torch.equal(i1, i2) and torch.equal(s1, s2)
+
+
+def test_config2_100k_768(dev):
+    """BASELINE config 2: 100k x 768 fp32 bank, 256 queries, top-32 (oracle on 16 of them)."""
+    N, D, nq, k = 100_000, 768, 256, 32
+    bank, g = _bank(N, D, seed=1234, scale=False)
+    meta = _meta(N, g)
+    q = _queries(bank, nq, g)
+    s, i = _search(dev, bank, meta, q, k)
+    sd, idn = _search(dev, bank, meta, q, k, force_dense=True)
+    assert torch.equal(i, idn) and torch.equal(s, sd)
+    sub = torch.cat([torch.arange(0, 8), torch.arange(nq - 8, nq)])
+    ri, rs = O.knn_exact_batch(bank, meta[:, 0], meta[:, 1], q[sub], k, NOW)
+    exact, n, ok = topk_equivalent(i[sub], s[sub], ri, rs)
+    assert ok and exact >= n - 1
+    # planted neighbours: query j < 128 is bank row + noise, so its top-1 must be that row
+    # size-independent properties: sorted descending, unique rows, in range
+    sc = s.cpu(); ic = i.cpu()
+    assert (sc[:, :-1] >= sc[:, 1:]).all()
+    assert all(len(set(r.tolist())) == k for r in ic)
+    assert (ic >= 0).all() and (ic < N).all()
+
+
+def test_search_with_location(dev):
+    N, D, nq, k = 4000, 32, 20, 8
+    bank, g = _bank(N, D, seed=5)
+    meta = _meta(N, g, decayed=True)
+    loc = torch.randn(N, 2, generator=g) * 3
+    qloc = torch.randn(nq, 2, generator=g) * 3
+    q = _queries(bank, nq, g)
+    ri, rs = O.knn_exact_batch(bank, meta[:, 0], meta[:, 1], q, k, NOW, locations=loc, query_locations=qloc)
+    s, i = _search(dev, bank, meta, q, k, loc=loc.to(dev), q_loc=qloc.to(dev))
+    exact, n, ok = topk_equivalent(i, s, ri, rs)
+    assert ok and exact >= n - 1
+
+
+def test_ties_resolve_to_lower_row(dev):
+    """Identical rows -> identical scores: the kernel orders ties by row index."""
+    bank = torch.ones(300, 16)
+    bank[7] = 2 * torch.ones(16); bank[7, 0] = 5.0
+    meta = torch.zeros(300, 4); meta[:, 0] = 1.0; meta[:, 1] = NOW
+    q = torch.ones(2, 16)
+    for force in (True, False):
+        s, i = _search(dev, bank, meta, q, 6, force_dense=force)
+        assert i[0].tolist() == [0, 1, 2, 3, 4, 5]
+
+
+def test_topk_merge(dev):
+    from aura_snn_rag_amd import ops
+    g = torch.Generator().manual_seed(0)
+    S, nq, k = 8, 50, 32
+    scores = torch.randn(S, nq, k, generator=g)
+    idx = torch.randperm(S * nq * k, generator=g).reshape(S, nq, k).to(torch.int32)
+    ms, mi = ops.topk_merge(scores.to(dev), idx.to(dev), k)
+    flat_s = scores.permute(1, 0, 2).reshape(nq, S * k)
+    flat_i = idx.permute(1, 0, 2).reshape(nq, S * k).long()
+    rs, ri = O.merge_topk(flat_s, flat_i, k)
+    assert torch.equal(ms.cpu(), rs) and torch.equal(mi.cpu().long(), ri)
+
+
+def _mk_hf(dev, D=32, M=2000, **kw):
+    from aura_snn_rag_amd.core import hippocampal as H
+    return H, H.HippocampalFormation(n_place_cells=10, n_time_cells=5, n_grid_cells=5, max_memories=M,
+                                     feature_dim=D, device="cuda", **kw)
+
+
+def test_formation_write_recall_and_centroids_vs_oracle(dev, monkeypatch):
+    """Whole write path (online centroid update + periodic rebuild) and both recall paths against
+    the OracleBank run with the same seeds and clock."""
+    H, hf = _mk_hf(dev)
+    monkeypatch.setattr(H.time, "time", lambda: NOW)
+    ob = O.OracleBank(2000, 32)
+    for b in (hf, ob):
+        b.centroids_k = 16
+        b.centroids_update_interval = 64
+    g = torch.Generator().manual_seed(0)
+    feats = torch.randn(600, 32, generator=g) * (2 * torch.rand(600, 1, generator=g))
+    torch.manual_seed(5)
+    for i in range(600):
+        ob.write(f"m{i}", feats[i], NOW)
+    torch.manual_seed(5)
+    for i in range(0, 600, 50):   # batched writes split themselves at rebuild boundaries
+        hf.create_episodic_memories([f"m{j}" for j in range(i, i + 50)], feats[i:i + 50])
+    assert hf.memory_count == 600 and hf._index_ready and ob.index_ready
+    assert torch.equal(hf.memory_features.cpu(), ob.features)
+    meta = hf.memory_metadata.cpu()
+    assert torch.equal(meta[:600, :2], ob.metadata[:600, :2])
+    agree = (meta[:600, 2] == ob.metadata[:600, 2]).float().mean().item()
+    assert agree >= 0.99, f"centroid assignment agreement {agree}"
+    assert torch.allclose(hf.centroids.cpu(), ob.centroids, rtol=1e-4, atol=1e-4) or agree < 1.0
+    # exact recall
+    hf.use_centroid_index = False; ob.use_centroid_index = False
+    q = feats[7] + 0.05 * torch.randn(32, generator=g)
+    res = hf.retrieve_similar_memories(q, k=10)
+    rows, sc = ob.recall(q, 10, NOW)
+    assert [r[0] for r in res] == [f"m{int(i)}" for i in rows]
+    assert torch.allclose(torch.tensor([r[1] for r in res]), sc, atol=1e-5)
+    # recall with location
+    loc = torch.tensor([0.3, -0.2])
+    res = hf.retrieve_similar_memories(q, location=loc, k=10)
+    rows, sc = ob.recall(q, 10, NOW, location=loc)
+    assert [r[0] for r in res] == [f"m{int(i)}" for i in rows]
+    # decay then candidate path (fixed-id semantics, see OracleBank docstring)
+    hf.decay_memories(0.1); ob.decay(0.1)
+    assert torch.equal(hf.memory_metadata.cpu()[:600, 0], ob.metadata[:600, 0])
+    hf.use_centroid_index = True; ob.use_centroid_index = True
+    if agree == 1.0:
+        for j in (7, 100, 333):
+            qq = feats[j] + 0.05 * torch.randn(32, generator=g)
+            res = hf.retrieve_similar_memories(qq, k=5)
+            rows, sc = ob.recall(qq, 5, NOW)
+            assert [r[0] for r in res] == [f"m{int(i)}" for i in rows]
+            assert torch.allclose(torch.tensor([r[1] for r in res]), sc, atol=1e-5)
+
+
+def test_formation_reference_known_answers(dev):
+    """Ports of the reference's own tests: tests/test_hippocampal_formation.py:61-79,
+    tests/test_hippocampal_index.py:13-91."""
+    H, hf = _mk_hf(dev, D=64, M=100000)
+    feats = torch.randn(5, 64)
+    for i in range(5):
+        hf.update_spatial_state(torch.randn(2, device=dev) * 5)
+        hf.create_episodic_memory(f"mem_{i}", f"evt_{i}", feats[i].to(dev))
+    assert hf.memory_count == 5
+    assert hf.retrieve_similar_memories(feats[0], k=1)[0][0] == "mem_0"
+    before = hf.memory_metadata[0, 0].item()
+    hf.decay_memories(0.1)
+    assert 0 < hf.memory_metadata[0, 0].item() < before
+
+    H, hf = _mk_hf(dev, D=4, M=100)
+    hf.centroids_k = 4
+    hf.centroids_update_interval = 1
+    torch.manual_seed(0)
+    for i in range(10):
+        hf.create_episodic_memory(f"A{i}", f"A{i}", torch.tensor([1.0, 0, 0, 0]) + 0.01 * torch.randn(4))
+    for i in range(10):
+        hf.create_episodic_memory(f"B{i}", f"B{i}", torch.tensor([0, 1.0, 0, 0]) + 0.01 * torch.randn(4))
+    hf.rebuild_centroids()
+    assert hf._index_ready and hf.memory_count == 20
+    res = hf.retrieve_similar_memories(torch.tensor([1.0, 0, 0, 0]), k=5)
+    assert len(res) == 5 and all(r[0].startswith("A") for r in res)
+
+    H, hf = _mk_hf(dev, D=4, M=50)
+    for i in range(3):
+        hf.create_episodic_memory(f"S{i}", f"S{i}", torch.tensor([float(i == 0), float(i == 1), 0.0, 0.0]))
+    assert hf.memory_count == 3 and hf._index_ready is False
+    assert len(hf.retrieve_similar_memories(torch.tensor([1.0, 0, 0, 0]), k=2)) == 2
+    assert hf.retrieve_similar_memories(torch.zeros(4), k=2) is not None
+
+
+def test_formation_full_bank_reference_overwrite(dev):
+    """Reference defect reproduced: a full bank overwrites slot 0 (hippocampal.py:200-202)."""
+    H, hf = _mk_hf(dev, D=8, M=4, use_centroid_index=False)
+    ob = O.OracleBank(4, 8, use_centroid_index=False)
+    feats = torch.randn(7, 8)
+    for i in range(7):
+        hf.create_episodic_memory(f"m{i}", "e", feats[i]); ob.write(f"m{i}", feats[i], NOW)
+    assert torch.equal(hf.memory_features.cpu(), ob.features) and hf.id_to_idx == ob.id_to_idx
+    res = hf.retrieve_similar_memories(feats[6], k=4)
+    assert res[0][0] == "m6" and len(res) == 4
+    H, hf = _mk_hf(dev, D=8, M=4, use_centroid_index=False, overflow='fifo')
+    for i in range(7):
+        hf.create_episodic_memory(f"m{i}", "e", feats[i])
+    assert torch.equal(hf.memory_features.cpu(), torch.stack([feats[4], feats[5], feats[6], feats[3]]))
+
+
+def test_rebuild_centroids_vs_oracle(dev):
+    H, hf = _mk_hf(dev, D=64, M=6000)
+    ob = O.OracleBank(6000, 64)
+    g = torch.Generator().manual_seed(3)
+    centers = torch.randn(40, 64, generator=g) * 3
+    feats = centers[torch.randint(0, 40, (5000,), generator=g)] + torch.randn(5000, 64, generator=g)
+    hf.use_centroid_index = False; ob.use_centroid_index = False
+    hf.create_episodic_memories([f"m{i}" for i in range(5000)], feats)
+    for i in range(5000):
+        ob.features[i] = feats[i]
+    ob.count = 5000
+    ob.metadata[:5000, 0] = 1.0
+    hf.use_centroid_index = True; ob.use_centroid_index = True
+    perm = torch.randperm(5000, generator=g)
+    hf.rebuild_centroids(perm=perm); ob.rebuild_centroids(perm=perm)
+    a = hf.memory_metadata.cpu()[:5000, 2]; b = ob.metadata[:5000, 2]
+    agree = (a == b).float().mean().item()
+    assert agree >= 0.995, f"assignment agreement {agree}"
+    assert torch.allclose(hf.centroid_counts.cpu().sum(), torch.tensor(5000.0))
+    big = ob.centroid_counts > 5
+    assert torch.allclose(hf.centroids.cpu()[big], ob.centroids[big], rtol=1e-3, atol=5e-2)
+
+
+def test_gather_and_state_dict_roundtrip(dev):
+    H, hf = _mk_hf(dev, D=16, M=64, use_centroid_index=False)
+    feats = torch.randn(10, 16)
+    hf.create_episodic_memories([f"m{i}" for i in range(10)], feats)
+    rows = torch.tensor([[0, 3, -1], [9, 9, 1]], dtype=torch.int32, device=dev)
+    got = hf.gather_features(rows).cpu()
+    assert torch.equal(got[0, 0], feats[0]) and torch.equal(got[0, 2], torch.zeros(16)) and torch.equal(got[1, 0], feats[9])
+    H2, hf2 = _mk_hf(dev, D=16, M=64, use_centroid_index=False)
+    hf2.load_state_dict(hf.state_dict())
+    hf2.memory_count = hf.memory_count          # the reference does not persist the count either
+    hf2._idx_to_id[:10] = [f"m{i}" for i in range(10)]
+    assert hf2.retrieve_similar_memories(feats[4], k=1)[0][0] == "m4"
