@@ -619,7 +619,8 @@ __global__ __launch_bounds__(SEL_THREADS) void topk_select_kernel(const SelectAr
             idx = a.row_begin + (j / a.blk) * (int64_t)a.blk * a.step + j % a.blk;
             if (idx >= a.row_end) { s = -INFINITY; idx = 0x7fffffff; }
         }
-        if (idx < 0) { s = -INFINITY; idx = 0x7fffffff; }
+        // -inf marks "not a candidate" (masked by the centroid probe, out of range, padding)
+        if (idx < 0 || s == -INFINITY) { s = -INFINITY; idx = 0x7fffffff; }
         s_keys[i] = ((unsigned long long)ord_key(s) << 32) | (0xffffffffu - (uint32_t)idx);
     }
     const int k = a.k < n ? a.k : n;  // winners available in this chunk

@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--k", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
-    ap.add_argument("--cpu-queries", type=int, default=32)
+    ap.add_argument("--cpu-queries", type=int, default=24)
     return ap.parse_args()
 
 
@@ -122,7 +122,13 @@ def cpu_baseline(bank_rows, dim, k, nq_sample):
     """The oracle's recall at the REFERENCE's cost model (bank re-normalised per query,
     hippocampal.py:273-279) on the host cores; bit-identical to the reference (tests)."""
     from oracle import aura_oracle as O
-    torch.set_num_threads(os.cpu_count() or 1)
+    # the GPU box gives a 1-GPU job a 16-core CPU share (all 256 host cores are visible, but
+    # oversubscribing them is slower than using the share)
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(16, ncpu)))
     g = torch.Generator().manual_seed(1234)
     ob = O.OracleBank(bank_rows, dim, use_centroid_index=False)
     ob.features = torch.randn(bank_rows, dim, generator=g)

@@ -263,3 +263,45 @@ def test_gather_and_state_dict_roundtrip(dev):
     hf2.memory_count = hf.memory_count          # the reference does not persist the count either
     hf2._idx_to_id[:10] = [f"m{i}" for i in range(10)]
     assert hf2.retrieve_similar_memories(feats[4], k=1)[0][0] == "m4"
+
+
+def test_candidate_path_clustered_vs_oracle(dev, monkeypatch):
+    """Centroid-candidate recall on clustered data, where the probed centroids own rows (the
+    masked scan is exercised, not the empty-candidate fallback)."""
+    H, hf = _mk_hf(dev, D=32, M=4000)
+    monkeypatch.setattr(H.time, "time", lambda: NOW)
+    ob = O.OracleBank(4000, 32)
+    g = torch.Generator().manual_seed(11)
+    centers = torch.randn(24, 32, generator=g) * 4
+    lab = torch.randint(0, 24, (3000,), generator=g)
+    feats = centers[lab] + 0.5 * torch.randn(3000, 32, generator=g)
+    for b in (hf, ob):
+        b.centroids_k = 32
+        b.use_centroid_index = False
+    hf.create_episodic_memories([f"m{i}" for i in range(3000)], feats)
+    for i in range(3000):
+        ob.features[i] = feats[i]; ob.idx_to_id[i] = f"m{i}"
+    ob.count = 3000; ob.metadata[:3000, 0] = 1.0; ob.metadata[:3000, 1] = NOW
+    perm = torch.randperm(3000, generator=g)
+    for b in (hf, ob):
+        b.use_centroid_index = True
+    hf.rebuild_centroids(perm=perm); ob.rebuild_centroids(perm=perm)
+    agree = (hf.memory_metadata.cpu()[:3000, 2] == ob.metadata[:3000, 2]).float().mean().item()
+    assert agree == 1.0, f"assignment agreement {agree} (clusters are well separated)"
+    n_masked = 0
+    qs = centers[:12] + 0.3 * torch.randn(12, 32, generator=g)
+    for qq in qs:
+        cand = ob.candidates(qq)
+        rows, sc = ob.recall(qq, 7, NOW)
+        res = hf.retrieve_similar_memories(qq, k=7)
+        if cand is not None:
+            n_masked += 1
+            assert cand.numel() < 3000
+        assert [r[0] for r in res] == [f"m{int(i)}" for i in rows]
+        assert torch.allclose(torch.tensor([r[1] for r in res]), sc, atol=1e-5)
+    assert n_masked >= 6
+    # batched form agrees with the per-query form
+    s, r = hf.recall_batch(qs, k=7)
+    for j, qq in enumerate(qs):
+        rows, sc = ob.recall(qq, 7, NOW)
+        assert r[j].cpu().long().tolist() == rows.tolist()
