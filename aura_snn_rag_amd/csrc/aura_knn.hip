@@ -22,6 +22,7 @@
 // top-k (ties -> lower row).  The result is independent of append order.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/aura_hip.h"
 
@@ -189,6 +190,9 @@ constexpr int LDS_STRIDE = 36;  // floats per LDS row: 144 B keeps ds_read_b128 
 constexpr int MODE_DENSE = 0;
 constexpr int MODE_FILTER = 1;
 constexpr int MODE_ASSIGN = 2;
+// per-query candidate counters live on separate 128-byte lines: ~800 atomics per query per
+// launch would otherwise serialise 32 queries' traffic on one L2 line
+constexpr int CNT_STRIDE = 32;
 
 struct ScanArgs {
     const float* bank;
@@ -220,6 +224,7 @@ struct ScanArgs {
     // ASSIGN mode (k-means): "queries" are centroids; assign_out[row] = argmin_c(|c|^2 - 2 x.c)
     const float* qnorm2;    // [nq]
     int32_t* assign_out;    // [rows]
+    int dbg;                // timing ablations (AURA_SCAN_DBG), results invalid when non-zero
 };
 
 template <int WQ, int WR, int RT, int MODE, bool VEC4>
@@ -297,9 +302,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void knn_scan_kernel(const ScanArgs a
     const int64_t KT = (D + BK - 1) / BK;
     load_tile(0);
     for (int64_t kt = 0; kt < KT; ++kt) {
-        store_tile();
-        __syncthreads();
-        if (kt + 1 < KT) load_tile((kt + 1) * BK);
+        if (!(a.dbg & 2) || kt == 0) {
+            store_tile();
+            __syncthreads();
+        }
+        if (kt + 1 < KT && !(a.dbg & 1)) load_tile((kt + 1) * BK);
         const float* qrow = Qs + (wq * 32 + li) * LDS_STRIDE + 4 * lh;
         const float* brow = Bs + ((wr * RT) * 32 + li) * LDS_STRIDE + 4 * lh;
 #pragma unroll
@@ -319,7 +326,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void knn_scan_kernel(const ScanArgs a
                 }
             }
         }
-        __syncthreads();
+        if (!(a.dbg & 2)) __syncthreads();
     }
 
     // ---- epilogue on the accumulators ------------------------------------------------------
@@ -382,6 +389,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void knn_scan_kernel(const ScanArgs a
         iq[e] = q < a.nq ? a.inv_q[q] : 0.0f;
         thr[e] = (MODE == MODE_FILTER && q < a.nq) ? a.thr[q] : 0xffffffffu;
     }
+    // pass 1: turn every accumulator into its combined score; remember which pairs are candidates
+    unsigned long long pass = 0ull;   // bit r*16+e
 #pragma unroll
     for (int r = 0; r < RT; ++r) {
         const int lrow = (wr * RT + r) * 32 + li;
@@ -424,12 +433,37 @@ __global__ __launch_bounds__(SCAN_THREADS) void knn_scan_kernel(const ScanArgs a
                     a.dense[(int64_t)q * a.dense_ld + (int64_t)blockIdx.x * BR + lrow] =
                         cand ? comb : -INFINITY;
             } else {
-                if (cand && ord_key(comb) >= thr[e]) {
-                    const int pos = atomicAdd(a.cnt + q, 1);
-                    if (pos < a.cap) {
-                        a.cand_scores[(int64_t)q * a.cap + pos] = comb;
-                        a.cand_idx[(int64_t)q * a.cap + pos] = (int32_t)row;
+                acc[r][e] = comb;
+                if (cand && ord_key(comb) >= thr[e]) pass |= 1ull << (r * 16 + e);
+            }
+        }
+    }
+    if (MODE == MODE_FILTER && pass != 0ull) {
+        // pass 2: one slot reservation per (lane, query): up to 16 independent atomics are in
+        // flight together instead of one blocking round trip per candidate
+        int pos[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            int n = 0;
+#pragma unroll
+            for (int r = 0; r < RT; ++r) n += (int)((pass >> (r * 16 + e)) & 1ull);
+            const int q = q0 + wq * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            pos[e] = n > 0 ? atomicAdd(a.cnt + (int64_t)q * CNT_STRIDE, n) : 0;
+        }
+        // pass 3: write the candidates
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int q = q0 + wq * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            int p = pos[e];
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                if ((pass >> (r * 16 + e)) & 1ull) {
+                    if (p < a.cap) {
+                        a.cand_scores[(int64_t)q * a.cap + p] = acc[r][e];
+                        a.cand_idx[(int64_t)q * a.cap + p] =
+                            (int32_t)(row0 + (wr * RT + r) * 32 + li);
                     }
+                    ++p;
                 }
             }
         }
@@ -596,7 +630,7 @@ __global__ __launch_bounds__(SEL_THREADS) void topk_select_kernel(const SelectAr
     const int c = blockIdx.x;
     int64_t total = a.n_max;
     if (a.src_cnt) {
-        const int64_t cnt = a.src_cnt[q];
+        const int64_t cnt = a.src_cnt[(int64_t)q * CNT_STRIDE];
         if (cnt > a.n_max) {
             if (tid == 0 && a.overflow) *a.overflow = 1;
         } else {
@@ -706,7 +740,7 @@ __global__ __launch_bounds__(SEL_THREADS) void topk_select_kernel(const SelectAr
             a.dst_idx[o] = idx;
         }
         if (tid == 0) {
-            if (a.cnt_out) atomicAdd(a.cnt_out + q, a.k);
+            if (a.cnt_out) atomicAdd(a.cnt_out + (int64_t)q * CNT_STRIDE, a.k);
             if (a.thr_out && k == a.k && k > 0) atomicMax(a.thr_out + q, (uint32_t)(kth >> 32));
         }
         return;
@@ -763,7 +797,7 @@ constexpr int CAND_CAP_MIN = 8192;      // filter-path candidate slots per query
 struct Workspace {
     float* inv_q;        // [QBLOCK]
     uint32_t* thr;       // [QBLOCK]
-    int32_t* cnt;        // [QBLOCK]
+    int32_t* cnt;        // [QBLOCK][CNT_STRIDE]
     uint32_t* probe;     // [QBLOCK][8]
     float* cand_scores;  // [qb][cap]
     int32_t* cand_idx;   // [qb][cap]
@@ -795,7 +829,7 @@ inline Workspace carve(void* base, int64_t N, int64_t nq, int k) {
     w.cap2 = (int)align_up(((int64_t)w.cap + SEL_LDS_KEYS - 1) / SEL_LDS_KEYS * k, 64);
     w.inv_q = reinterpret_cast<float*>(take(QBLOCK * 4));
     w.thr = reinterpret_cast<uint32_t*>(take(QBLOCK * 4));
-    w.cnt = reinterpret_cast<int32_t*>(take(QBLOCK * 4));
+    w.cnt = reinterpret_cast<int32_t*>(take(QBLOCK * CNT_STRIDE * 4));
     w.probe = reinterpret_cast<uint32_t*>(take(QBLOCK * 32));
     w.cand_scores = reinterpret_cast<float*>(take((int64_t)qb * w.cap * 4));
     w.cand_idx = reinterpret_cast<int32_t*>(take((int64_t)qb * w.cap * 4));
@@ -834,7 +868,10 @@ struct ProfileState {
 ProfileState g_prof;
 
 template <int WQ, int WR, int RT>
-int launch_scan(const ScanArgs& a, int mode, int64_t ntiles_grid, hipStream_t s) {
+int launch_scan(const ScanArgs& a_in, int mode, int64_t ntiles_grid, hipStream_t s) {
+    ScanArgs a = a_in;
+    static const int dbg = getenv("AURA_SCAN_DBG") ? atoi(getenv("AURA_SCAN_DBG")) : 0;
+    a.dbg = dbg;
     constexpr int BQ = WQ * 32, BR = WR * RT * 32;
     const size_t lds = (size_t)(BQ + BR) * LDS_STRIDE * sizeof(float);
     const dim3 grid((unsigned)ntiles_grid, (unsigned)((a.nq + BQ - 1) / BQ));
@@ -952,7 +989,7 @@ int aura_knn_search_ex(const float* bank, const float* inv_norm, const float* me
         hipLaunchKernelGGL(row_inv_norm_kernel, dim3((unsigned)((nqb + 3) / 4)), dim3(256), 0, s,
                            qptr, w.inv_q, (int64_t)nqb, D);
         if ((rc = check_launch())) return rc;
-        if (hipMemsetAsync(w.cnt, 0, QBLOCK * 4, s) != hipSuccess) return AURA_E_LAUNCH;
+        if (hipMemsetAsync(w.cnt, 0, QBLOCK * CNT_STRIDE * 4, s) != hipSuccess) return AURA_E_LAUNCH;
         if (hipMemsetAsync(w.thr, 0, QBLOCK * 4, s) != hipSuccess) return AURA_E_LAUNCH;
 
         ScanArgs a{};
