@@ -174,20 +174,25 @@ class HippocampalFormation(nn.Module):
         return {"time_cells": time_rates.flatten(), "elapsed": elapsed}
 
     # ------------------------------------------------------------------ write
-    def _next_slot(self) -> int:
-        if self.memory_count >= self.max_memories:
-            if self._overflow == 'reference':
-                return self.memory_count % self.max_memories      # == 0, as the reference (:200-202)
-            slot = self._write_cursor % self.max_memories
-            self._write_cursor += 1
-            return slot
-        slot = self.memory_count
-        self.memory_count += 1
-        return slot
+    def _plan_slots(self, n: int):
+        """Slots for the next n writes plus the counters they leave behind (nothing is mutated
+        until the kernel launch has been accepted)."""
+        count, cursor, slots = self.memory_count, self._write_cursor, []
+        for _ in range(n):
+            if count >= self.max_memories:
+                if self._overflow == 'reference':
+                    slots.append(count % self.max_memories)   # == 0, as the reference (:200-202)
+                else:
+                    slots.append(cursor % self.max_memories)
+                    cursor += 1
+            else:
+                slots.append(count)
+                count += 1
+        return slots, count, cursor
 
     def _write_rows(self, ids: Sequence[str], feats: torch.Tensor, now: float) -> None:
         """Write a run of rows that contains no centroid-rebuild boundary."""
-        slots = [self._next_slot() for _ in ids]
+        slots, new_count, new_cursor = self._plan_slots(len(ids))
         slot_t = torch.tensor(slots, dtype=torch.int64, device=self.device)
         online = self.use_centroid_index and self._index_ready
         eff_k = min(self.centroids_k, self.centroids.shape[0])
@@ -198,6 +203,7 @@ class HippocampalFormation(nn.Module):
                        centroids=self.centroids if online else None,
                        centroid_counts=self.centroid_counts if online else None,
                        eff_k=eff_k if online else 0)
+        self.memory_count, self._write_cursor = new_count, new_cursor
         lo, hi = min(slots), max(slots)
         if self._norms_valid_upto >= lo:      # the kernel refreshed 1/||row|| of the written slots
             self._norms_valid_upto = max(self._norms_valid_upto, hi + 1)

@@ -159,8 +159,7 @@ def bank_write(bank, loc, meta, inv_norm, feats, slots, cur_loc, now: float,
     if feats.shape != (n, D) or slots.numel() != n or meta.shape != (M, 4) or \
             loc.shape[0] != M or cur_loc.numel() != sd or inv_norm.numel() != M:
         raise ValueError("bank_write: shape mismatch")
-    if n and (int(slots.min()) < 0 or int(slots.max()) >= M):
-        raise ValueError("bank_write: slot out of range")
+    # slots are planned on the host by HippocampalFormation._plan_slots (always within [0, M))
     if centroids is not None:
         _need(centroids, "centroids", torch.float32)
         _need(centroid_counts, "centroid_counts", torch.float32)

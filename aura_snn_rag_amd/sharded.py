@@ -66,10 +66,12 @@ class ShardedRecall:
             allq = queries
         s, r = self.local_search(allq, k)                       # [n, k] over this shard
         n = allq.shape[0]
-        gs = torch.empty(S, n, k, dtype=s.dtype, device=s.device)
-        gr = torch.empty(S, n, k, dtype=r.dtype, device=r.device)
+        # flat [S*n, k] outputs (concatenation along dim 0 is the layout both RCCL and gloo accept)
+        gs = torch.empty(S * n, k, dtype=s.dtype, device=s.device)
+        gr = torch.empty(S * n, k, dtype=r.dtype, device=r.device)
         dist.all_gather_into_tensor(gs, s.contiguous(), group=self.group)
         dist.all_gather_into_tensor(gr, r.contiguous(), group=self.group)
+        gs, gr = gs.view(S, n, k), gr.view(S, n, k)
         if all_gather_queries:                                   # keep only this rank's queries
             lo = self.rank * nq
             gs = gs[:, lo:lo + nq].contiguous()

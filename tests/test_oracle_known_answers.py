@@ -1,0 +1,63 @@
+"""The reference's own known-answer tests for the path, restated against the oracle
+(SURVEY.md section 8c): tests/core/language_zone/test_gif_neuron.py:14-78,
+tests/test_hippocampal_formation.py:61-79, tests/test_hippocampal_index.py:13-91,
+tests/test_izhikevich.py:6-13, test_synapsis.py:83-92."""
+import torch
+
+from oracle import aura_oracle as O
+
+NOW = 1.7e9
+
+
+def _gif1(x, L):
+    w, b = torch.ones(1, 1), torch.zeros(1)
+    return O.gif_forward(x, w, b, L=L, decay=1.0, threshold=1.0)
+
+
+def test_gif_multi_bit_clip_accumulate():
+    out, (v, _) = _gif1(torch.tensor([[[5.5]]]), 16)
+    assert out.item() == 5.0 and torch.isclose(v, torch.tensor([[0.5]]), atol=1e-5).all()
+    out, _ = _gif1(torch.tensor([[[10.0]]]), 4)
+    assert out.item() == 4.0
+    out, (v, _) = _gif1(torch.tensor([[[0.6], [0.6]]]), 16)
+    assert out[0, 0, 0].item() == 0.0 and out[0, 1, 0].item() == 1.0
+    assert torch.isclose(v, torch.tensor([[0.2]]), atol=1e-5).all()
+
+
+def test_izhikevich_tonic_spiking():
+    v, u = O.izh_initial_state(1, 0.2)
+    s, _, _ = O.izh_run(torch.full((1, 200), 14.0), v, u, 0.02, 0.2, -65.0, 6.0, 0.2)
+    assert s.sum().item() > 0
+
+
+def test_synapsis_zero_in_zero_out():
+    assert O.synapsis_forward(torch.zeros(2, 5, 8), torch.randn(4, 8), torch.zeros(4)).abs().sum() == 0
+
+
+def test_store_five_recall_first():
+    ob = O.OracleBank(100000, 64)
+    feats = torch.randn(5, 64)
+    for i in range(5):
+        ob.write(f"mem_{i}", feats[i], NOW)
+    assert ob.recall_ids(feats[0], 1, NOW)[0][0] == "mem_0"
+
+
+def test_centroid_index_biases_retrieval_and_fallback_and_decay():
+    torch.manual_seed(0)
+    ob = O.OracleBank(100, 4, centroids_k=4, centroids_update_interval=1)
+    for i in range(10):
+        ob.write(f"A{i}", torch.tensor([1.0, 0, 0, 0]) + 0.01 * torch.randn(4), NOW)
+    for i in range(10):
+        ob.write(f"B{i}", torch.tensor([0, 1.0, 0, 0]) + 0.01 * torch.randn(4), NOW)
+    ob.rebuild_centroids()
+    res = ob.recall_ids(torch.tensor([1.0, 0, 0, 0]), 5, NOW)
+    assert len(res) == 5 and all(r[0].startswith("A") for r in res)
+    small = O.OracleBank(50, 4)
+    for i in range(3):
+        small.write(f"S{i}", torch.tensor([float(i == 0), float(i == 1), 0.0, 0.0]), NOW)
+    assert not small.index_ready and len(small.recall_ids(torch.tensor([1.0, 0, 0, 0]), 2, NOW)) == 2
+    one = O.OracleBank(10, 4)
+    one.write("X", torch.zeros(4), NOW)
+    before = one.metadata[0, 0].item()
+    one.decay(0.1)
+    assert 0 < one.metadata[0, 0].item() < before

@@ -1,0 +1,106 @@
+"""Pins the oracle to the upstream reference, imported unmodified (build container only; the
+reference does not travel to the GPU box, where these tests skip)."""
+import pytest
+import torch
+
+from oracle import _ref_loader as L
+from oracle import aura_oracle as O
+
+pytestmark = pytest.mark.skipif(not L.available(), reason="reference checkout not mounted")
+NOW = 1.7e9 + 777.0
+
+
+def test_neuron_loops_bit_exact():
+    N = L.load("base.neuron")
+    torch.manual_seed(0)
+    I = 20 * torch.rand(300, 77)
+    izh = N.IzhikevichNeuron(0.02, 0.2, -65, 8, 0.2)
+    ref = izh(I)
+    v, u = O.izh_initial_state(300, 0.2)
+    s, v, u = O.izh_run(I, v, u, 0.02, 0.2, -65, 8, 0.2)
+    assert torch.equal(ref, s) and torch.equal(izh.v, v) and torch.equal(izh.u, u)
+    ad = N.AdExNeuron(a=2.0, b=60.0)
+    Ia = 600 * torch.rand(32, 150)
+    ra = ad(Ia)
+    p = O.adex_params(a=2.0, b=60.0)
+    sa, V, w = O.adex_run(Ia, torch.full((32,), float(p[1])), torch.zeros(32), p)
+    assert torch.equal(ra, sa) and torch.equal(ad.V, V) and torch.equal(ad.w, w)
+    lif = N.VectorizedLIFNeuron(16, 0.9, 0.6)
+    mem = torch.zeros(3, 16)
+    for _ in range(4):
+        x = torch.randn(3, 16)
+        rs, rm = lif(x)
+        os_, mem = O.lif_step(x, mem, lif.beta, lif.threshold)
+        assert torch.equal(rs.detach(), os_) and torch.equal(rm.detach(), mem)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gif_and_ffn_bit_exact(dtype):
+    G = L.load("src.core.language_zone.gif_neuron")
+    F = L.load("src.core.language_zone.snn_ffn")
+    torch.manual_seed(1)
+    g = G.GIFNeuron(24, 40, L=8).to(dtype)
+    x = (torch.randn(4, 9, 24) * 3).to(dtype)
+    with torch.no_grad():
+        rs, (rv, rt) = g(x)
+        os_, (ov, ot) = O.gif_forward(x, g.linear.weight, g.linear.bias, L=8, decay=g.decay)
+    assert torch.equal(rs, os_) and torch.equal(rv, ov) and torch.equal(rt, ot)
+    bg = G.BalancedGIFNeuron(24, 40, L=8).to(dtype)
+    with torch.no_grad():
+        rs, _ = bg(x)
+        os_, _ = O.balanced_gif_forward(x, bg.linear_exc.weight, bg.linear_exc.bias, bg.linear_inh.weight,
+                                        bg.linear_inh.bias, L=8, decay=bg.decay)
+    assert torch.equal(rs, os_)
+    if dtype == torch.float32:
+        ffn = F.SNNFFN(32, 96, num_timesteps=4, L=8).eval()
+        xx = torch.randn(2, 8, 32)
+        with torch.no_grad():
+            assert torch.equal(ffn(xx), O.snnffn_forward(xx, dict(ffn.state_dict()), T=4, L=8))
+
+
+def test_bank_bit_exact_and_defects_pinned():
+    H = L.load("core.hippocampal")
+    H.time.time = lambda: NOW
+    D, M = 16, 500
+    ref = H.HippocampalFormation(n_place_cells=4, n_time_cells=3, n_grid_cells=3, max_memories=M, feature_dim=D, device="cpu")
+    ob = O.OracleBank(M, D)
+    for b in (ref, ob):
+        b.centroids_k = 8
+        b.centroids_update_interval = 32
+    feats = torch.randn(200, D) * torch.rand(200, 1) * 2
+    torch.manual_seed(9)
+    for i in range(200):
+        ref.create_episodic_memory(f"m{i}", "e", feats[i])
+    torch.manual_seed(9)
+    for i in range(200):
+        ob.write(f"m{i}", feats[i], NOW)
+    assert torch.equal(ref.memory_features, ob.features) and torch.equal(ref.memory_metadata, ob.metadata)
+    assert torch.equal(ref.centroids, ob.centroids) and torch.equal(ref.centroid_counts, ob.centroid_counts)
+    q = feats[3] + 0.05 * torch.randn(D)
+    ref.use_centroid_index = ob.use_centroid_index = False
+    assert ref.retrieve_similar_memories(q, k=7) == ob.recall_ids(q, 7, NOW)
+    loc = torch.tensor([1.0, -1.0])
+    assert ref.retrieve_similar_memories(q, location=loc, k=7) == ob.recall_ids(q, 7, NOW, location=loc)
+    ref.use_centroid_index = ob.use_centroid_index = True
+    r = ref.retrieve_similar_memories(q, k=5)
+    rows, sc = ob.recall(q, 5, NOW)
+    assert [x[1] for x in r] == [float(s) for s in sc]           # scores agree ...
+    cand = ob.candidates(q)
+    if cand is not None and not torch.equal(cand[:5], torch.arange(5)):
+        assert [x[0] for x in r] != [f"m{int(i)}" for i in rows]  # ... ids are wrong upstream (pinned defect)
+    # full bank always overwrites slot 0 (pinned defect, reproduced)
+    ref2 = H.HippocampalFormation(n_place_cells=4, n_time_cells=3, n_grid_cells=3, max_memories=3, feature_dim=D,
+                                  device="cpu", use_centroid_index=False)
+    ob2 = O.OracleBank(3, D, use_centroid_index=False)
+    for i in range(6):
+        ref2.create_episodic_memory(f"m{i}", "e", feats[i]); ob2.write(f"m{i}", feats[i], NOW)
+    assert torch.equal(ref2.memory_features, ob2.features) and ref2.id_to_idx == ob2.id_to_idx
+
+
+def test_zone_and_addition_linear_bit_exact():
+    A = L.load("src.maths.addition_linear")
+    torch.manual_seed(2)
+    al = A.AdditionLinear(20, 30, bias=True)
+    x = torch.randn(5, 20)
+    with torch.no_grad():
+        assert torch.equal(al(x), O.addition_linear(x, al.weight_patterns, al.bias))
