@@ -207,8 +207,15 @@ struct ScanArgs {
     int64_t row_begin, row_end;  // scanned row range
     int64_t D;
     int nq;                 // queries in this block
-    int tile_step;          // DENSE: tile = blockIdx.x * tile_step; FILTER: sample tiles are skipped
-    int n_sample_tiles;     // FILTER: tiles t with t % tile_step == 0 && t / tile_step < this are skipped
+    // Sampling geometry.  Rows are grouped in LOGICAL tiles of `logical_rows` (128); logical tile
+    // L is a sample tile iff L % tile_step == 0 && L / tile_step < n_sample_tiles.
+    //   DENSE : workgroup bx scores kernel-tile (bx % sub) of logical tile (bx / sub) * tile_step,
+    //           sub = logical_rows / BR; dense column = bx * BR + local row
+    //   FILTER: every row that is not in a sample tile
+    int tile_step;
+    int n_sample_tiles;
+    int logical_rows;
+    int64_t n_items;        // FILTER v2: number of non-sample 32-row tiles in [row_begin, row_end)
     // DENSE output
     float* dense;           // [nq][dense_ld]; column = blockIdx.x * BR + local row
     int64_t dense_ld;
@@ -238,13 +245,18 @@ __global__ __launch_bounds__(SCAN_THREADS) void knn_scan_kernel(const ScanArgs a
     float* Qs = smem;                    // [BQ][LDS_STRIDE]
     float* Bs = smem + BQ * LDS_STRIDE;  // [BR][LDS_STRIDE]
 
-    int64_t tile = blockIdx.x;
+    int64_t row0;
     if (MODE == MODE_DENSE) {
-        tile *= a.tile_step;
-    } else if (a.tile_step > 0 && tile % a.tile_step == 0 && tile / a.tile_step < a.n_sample_tiles) {
-        return;  // scored densely by the sample pass
+        const int sub = a.logical_rows / BR;   // kernel tiles per logical tile (>= 1)
+        row0 = a.row_begin + ((int64_t)blockIdx.x / sub) * a.tile_step * a.logical_rows +
+               ((int64_t)blockIdx.x % sub) * BR;
+    } else {
+        const int64_t tile = blockIdx.x;       // FILTER / ASSIGN: BR == logical_rows
+        if (MODE == MODE_FILTER && a.tile_step > 0 && tile % a.tile_step == 0 &&
+            tile / a.tile_step < a.n_sample_tiles)
+            return;  // scored densely by the sample pass
+        row0 = a.row_begin + tile * BR;
     }
-    const int64_t row0 = a.row_begin + tile * BR;
     const int q0 = blockIdx.y * BQ;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
@@ -467,6 +479,236 @@ __global__ __launch_bounds__(SCAN_THREADS) void knn_scan_kernel(const ScanArgs a
                 }
             }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Main scan, v2: persistent FILTER kernel for 256-query blocks.
+//   * one 512-thread workgroup per CU walks a balanced, contiguous span of the non-sample 32-row
+//     tiles (4 tiles = 128 rows per chunk), so the chip is evenly loaded whatever N is;
+//   * LDS is double buffered (2 x 54 KiB): one barrier per 32-deep k-tile; the next k-tile's
+//     global loads are in flight during the whole compute phase and are written to the other
+//     buffer by the two SIMD partners at DIFFERENT points of their MFMA streams (waves 0-3
+//     before, waves 4-7 after their first 16 MFMAs), so one partner always feeds the matrix pipe;
+//   * A/B fragments for MFMA group kk+1 are read from LDS before the 16 MFMAs of group kk.
+// Arithmetic (k order of every dot product, epilogue) is identical to knn_scan_kernel, so the
+// dense and filter paths return bit-identical results.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int64_t filter_tile_of(int64_t j, int step, int ns) {
+    // j-th non-sample 32-row tile -> 32-row tile index (sample logical tiles hold 4 of them)
+    const int64_t s = (int64_t)step * 4, per = s - 4;
+    if (ns > 0 && j < (int64_t)ns * per) return (j / per) * s + 4 + (j % per);
+    return (int64_t)ns * s + (j - (int64_t)ns * per);
+}
+
+template <bool VEC4>
+__global__ __launch_bounds__(SCAN_THREADS) void knn_scan_filter_v2(const ScanArgs a) {
+    constexpr int BQ = 256, BRR = 128, RT = 4;
+    constexpr int TILE_FLOATS = (BQ + BRR) * LDS_STRIDE;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const buf0 = smem;
+    float* const buf1 = smem + TILE_FLOATS;
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    const int64_t D = a.D;
+    const int64_t KT = (D + BK - 1) / BK;
+    const int64_t lo = a.n_items * (int64_t)blockIdx.x / gridDim.x;
+    const int64_t hi = a.n_items * ((int64_t)blockIdx.x + 1) / gridDim.x;
+    if (lo >= hi) return;
+
+    // staging slots of this thread: 4 query rows (fixed) + 2 bank rows (per chunk)
+    const int srow = tid >> 3, scol = (tid & 7) * 4;
+    const float* qsrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = srow + 64 * i;
+        qsrc[i] = q < a.nq ? a.queries + (int64_t)q * D + scol : nullptr;
+    }
+    const int lds_slot = srow * LDS_STRIDE + scol;
+
+    for (int64_t c = lo; c < hi; c += RT) {
+        int64_t row0[RT];
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+            row0[r] = (c + r < hi)
+                          ? a.row_begin + filter_tile_of(c + r, a.tile_step, a.n_sample_tiles) * 32
+                          : a.row_end;
+        const float* bsrc[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int br = srow + 64 * i;            // 0..127
+            const int64_t row = row0[br >> 5] + (br & 31);
+            bsrc[i] = row < a.row_end ? a.bank + row * D + scol : nullptr;
+        }
+
+        f32x16 acc[RT];
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[r][e] = 0.0f;
+
+        float4 pre[6];
+        auto gload = [&](int64_t k0) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const float* src = i < 4 ? qsrc[i] : bsrc[i - 4];
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                const int64_t k = k0 + scol;
+                if (src) {
+                    if (VEC4) {
+                        if (k < D) v = *reinterpret_cast<const float4*>(src + k0);
+                    } else {
+                        if (k + 0 < D) v.x = src[k0 + 0];
+                        if (k + 1 < D) v.y = src[k0 + 1];
+                        if (k + 2 < D) v.z = src[k0 + 2];
+                        if (k + 3 < D) v.w = src[k0 + 3];
+                    }
+                }
+                pre[i] = v;
+            }
+        };
+        auto lstore = [&](float* buf) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+                *reinterpret_cast<float4*>(buf + lds_slot + i * 64 * LDS_STRIDE) = pre[i];
+        };
+
+        gload(0);
+        lstore(buf0);
+        if (KT > 1) gload(BK);
+        __syncthreads();
+
+        for (int64_t kt = 0; kt < KT; ++kt) {
+            const float* cur = (kt & 1) ? buf1 : buf0;
+            float* nxt = (kt & 1) ? buf0 : buf1;
+            const bool has1 = kt + 1 < KT, has2 = kt + 2 < KT;
+            const float* qrow = cur + (wave * 32 + li) * LDS_STRIDE + 4 * lh;
+            const float* brow = cur + (BQ + li) * LDS_STRIDE + 4 * lh;
+
+            if (wave < 4) {                 // early stagers
+                if (has1) lstore(nxt);
+                if (has2) gload((kt + 2) * BK);
+            }
+            float4 av[2], bv[2][RT];
+            av[0] = *reinterpret_cast<const float4*>(qrow);
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+                bv[0][r] = *reinterpret_cast<const float4*>(brow + r * 32 * LDS_STRIDE);
+#pragma unroll
+            for (int kk = 0; kk < BK / 8; ++kk) {
+                const int s0 = kk & 1, s1 = s0 ^ 1;
+                if (kk + 1 < BK / 8) {
+                    av[s1] = *reinterpret_cast<const float4*>(qrow + (kk + 1) * 8);
+#pragma unroll
+                    for (int r = 0; r < RT; ++r)
+                        bv[s1][r] = *reinterpret_cast<const float4*>(brow + r * 32 * LDS_STRIDE +
+                                                                     (kk + 1) * 8);
+                }
+                const float af[4] = {av[s0].x, av[s0].y, av[s0].z, av[s0].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                    for (int r = 0; r < RT; ++r) {
+                        const float bf = j == 0 ? bv[s0][r].x : j == 1 ? bv[s0][r].y
+                                         : j == 2 ? bv[s0][r].z : bv[s0][r].w;
+                        acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j], bf, acc[r], 0, 0, 0);
+                    }
+                }
+                if (kk == 0 && wave >= 4) {  // late stagers: after their first 16 MFMAs
+                    if (has1) lstore(nxt);
+                    if (has2) gload((kt + 2) * BK);
+                }
+            }
+            __syncthreads();
+        }
+
+        // ---- epilogue: combined score + candidate append (same arithmetic as knn_scan_kernel) ----
+        uint32_t* s_mask = reinterpret_cast<uint32_t*>(smem);
+        if (a.probe_mask) {
+            for (int t = tid; t < BQ * 8; t += SCAN_THREADS) {
+                const int q = t >> 3;
+                s_mask[t] = q < a.nq ? a.probe_mask[(int64_t)q * 8 + (t & 7)] : 0u;
+            }
+            __syncthreads();
+        }
+        // per-lane query constants: re-read per chunk (L2 hits) rather than held in 32 VGPRs
+        float iq[16];
+        uint32_t thr[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int q = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            iq[e] = q < a.nq ? a.inv_q[q] : 0.0f;
+            thr[e] = q < a.nq ? a.thr[q] : 0xffffffffu;
+        }
+        unsigned long long pass = 0ull;
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            const int64_t row = row0[r] + li;
+            const bool vrow = row < a.row_end;
+            float inv_m = 0.f, strength = 0.f, tw = 0.f;
+            int cid = -1;
+            float lx[4] = {0.f, 0.f, 0.f, 0.f};
+            if (vrow) {
+                inv_m = a.inv_norm[row];
+                const float4 m = *reinterpret_cast<const float4*>(a.meta + row * 4);
+                strength = m.x;
+                const float age = a.now - m.y;
+                tw = 0.2f * expf(-age / 3600.0f);
+                cid = (int)m.z;
+                if (a.q_loc)
+                    for (int d = 0; d < a.sdims && d < 4; ++d) lx[d] = a.loc[row * a.sdims + d];
+            }
+            const bool cid_ok = cid >= 0 && cid < 256;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int q = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                const float sim = acc[r][e] * iq[e] * inv_m;
+                float comb = 0.5f * sim;
+                if (a.q_loc && q < a.nq) {
+                    float d2 = 0.0f;
+                    for (int d = 0; d < a.sdims && d < 4; ++d) {
+                        const float df = lx[d] - a.q_loc[(int64_t)q * a.sdims + d];
+                        d2 = d2 + df * df;
+                    }
+                    comb = comb + 0.3f * (1.0f / (1.0f + sqrtf(d2)));
+                }
+                comb = (comb + tw) * strength;
+                bool cand = vrow && q < a.nq;
+                if (a.probe_mask)
+                    cand = cand && cid_ok && ((s_mask[q * 8 + (cid >> 5)] >> (cid & 31)) & 1u);
+                acc[r][e] = comb;
+                if (cand && ord_key(comb) >= thr[e]) pass |= 1ull << (r * 16 + e);
+            }
+        }
+        if (pass != 0ull) {
+            int pos[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                int n = 0;
+#pragma unroll
+                for (int r = 0; r < RT; ++r) n += (int)((pass >> (r * 16 + e)) & 1ull);
+                const int q = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                pos[e] = n > 0 ? atomicAdd(a.cnt + (int64_t)q * CNT_STRIDE, n) : 0;
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int q = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                int p = pos[e];
+#pragma unroll
+                for (int r = 0; r < RT; ++r) {
+                    if ((pass >> (r * 16 + e)) & 1ull) {
+                        if (p < a.cap) {
+                            a.cand_scores[(int64_t)q * a.cap + p] = acc[r][e];
+                            a.cand_idx[(int64_t)q * a.cap + p] = (int32_t)(row0[r] + li);
+                        }
+                        ++p;
+                    }
+                }
+            }
+        }
+        if (a.probe_mask) __syncthreads();   // s_mask aliases the staging buffers
     }
 }
 
@@ -891,6 +1133,43 @@ int launch_scan(const ScanArgs& a_in, int mode, int64_t ntiles_grid, hipStream_t
     return check_launch();
 }
 
+inline int device_cu_count() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+// persistent FILTER scan for a 256-query block (a.n_items non-sample 32-row tiles)
+inline int launch_filter_v2(const ScanArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)2 * (256 + 128) * LDS_STRIDE * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(knn_scan_filter_v2<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(knn_scan_filter_v2<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return AURA_E_LAUNCH;
+        attr_set = true;
+    }
+    if (a.n_items <= 0) return AURA_OK;
+    int64_t grid = device_cu_count();
+    const int64_t chunks = (a.n_items + 3) / 4;
+    if (grid > chunks) grid = chunks;
+    const bool vec4 = (a.D % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.bank) & 15) == 0) &&
+                      ((reinterpret_cast<uintptr_t>(a.queries) & 15) == 0);
+    if (vec4)
+        hipLaunchKernelGGL(knn_scan_filter_v2<true>, dim3((unsigned)grid), dim3(SCAN_THREADS), lds, s, a);
+    else
+        hipLaunchKernelGGL(knn_scan_filter_v2<false>, dim3((unsigned)grid), dim3(SCAN_THREADS), lds, s, a);
+    return check_launch();
+}
+
 // bank rows per workgroup tile for a query block of nq
 inline int tile_rows_for(int nq) { return nq <= 64 ? 256 : 128; }
 inline int dispatch_scan(const ScanArgs& a, int mode, int64_t ntiles_grid, hipStream_t s) {
@@ -1015,9 +1294,9 @@ int aura_knn_search_ex(const float* bank, const float* inv_norm, const float* me
         sel.dst_scores = w.cand_scores; sel.dst_idx = w.cand_idx; sel.dst_qs = w.cap;
         sel.cnt_out = w.cnt; sel.row_end = N;
 
-        // filter path: expected candidates per query ~ k*N/sample_rows; aim for ~1024
-        int64_t sample_rows = (int64_t)k * N / 1024;
-        if (sample_rows < 4096) sample_rows = 4096;
+        // filter path: expected candidates per query ~ k*N/sample_rows; aim for <= ~512
+        int64_t sample_rows = (int64_t)k * N / 512;
+        if (sample_rows < 8192) sample_rows = 8192;
         const int64_t n_sample_tiles = (sample_rows + br - 1) / br;
         const bool dense_all = (flags & AURA_KNN_FORCE_DENSE) || n_sample_tiles * 4 > ntiles ||
                                n_sample_tiles * br > DENSE_COLS;
@@ -1030,6 +1309,7 @@ int aura_knn_search_ex(const float* bank, const float* inv_norm, const float* me
                 const int64_t nt = (ntiles - t0) < tiles_per_super ? (ntiles - t0) : tiles_per_super;
                 const int64_t cols = nt * br;
                 a.row_begin = t0 * br; a.tile_step = 1; a.n_sample_tiles = 0; a.dense_ld = cols;
+                a.logical_rows = br;
                 if ((rc = dispatch_scan(a, MODE_DENSE, nt, s))) return rc;
                 const int64_t nchunks = (cols + SEL_CHUNK - 1) / SEL_CHUNK;
                 sel.src_qs = cols; sel.src_inner = cols; sel.n_max = cols; sel.step = 1;
@@ -1045,7 +1325,14 @@ int aura_knn_search_ex(const float* bank, const float* inv_norm, const float* me
             const int tile_step = (int)(ntiles / n_sample_tiles);
             const int64_t cols = n_sample_tiles * br;
             a.tile_step = tile_step; a.n_sample_tiles = (int)n_sample_tiles; a.dense_ld = cols;
-            if ((rc = dispatch_scan(a, MODE_DENSE, n_sample_tiles, s))) return rc;
+            a.logical_rows = br;
+            if (nqb > 128) {
+                // 32-row kernel tiles: 4x the workgroups of the 128-row geometry, so the short
+                // sample pass covers the whole chip instead of a few CUs
+                if ((rc = launch_scan<8, 1, 1>(a, MODE_DENSE, n_sample_tiles * 4, s))) return rc;
+            } else {
+                if ((rc = dispatch_scan(a, MODE_DENSE, n_sample_tiles, s))) return rc;
+            }
             const int64_t nchunks = (cols + SEL_CHUNK - 1) / SEL_CHUNK;
             sel.src_qs = cols; sel.src_inner = cols; sel.n_max = cols; sel.step = tile_step;
             sel.row_begin = 0; sel.dst_off = 0; sel.thr_out = w.thr;
@@ -1053,7 +1340,13 @@ int aura_knn_search_ex(const float* bank, const float* inv_norm, const float* me
             // 2) main scan appends the rows that reach the bound (sample tiles are skipped)
             const bool prof = g_prof.on && g_prof.used < g_prof.cap;
             if (prof) (void)hipEventRecord(g_prof.start[g_prof.used], s);
-            if ((rc = dispatch_scan(a, MODE_FILTER, ntiles, s))) return rc;
+            static const bool force_v1 = getenv("AURA_SCAN_V1") != nullptr;
+            if (nqb > 128 && !force_v1) {
+                a.n_items = (N + 31) / 32 - 4 * n_sample_tiles;
+                if ((rc = launch_filter_v2(a, s))) return rc;
+            } else {
+                if ((rc = dispatch_scan(a, MODE_FILTER, ntiles, s))) return rc;
+            }
             if (prof) (void)hipEventRecord(g_prof.stop[g_prof.used++], s);
             cur_n = w.cap;
             cur_cnt = w.cnt;
