@@ -219,6 +219,8 @@ struct ScanArgs {
     // DENSE output
     float* dense;           // [nq][dense_ld]; column = blockIdx.x * BR + local row
     int64_t dense_ld;
+    float* gmax;            // optional [nq][gmax_ld]: max score of each 32-row group
+    int64_t gmax_ld;        //   (group = blockIdx.x * BR/32 + 32-row sub-tile of the workgroup)
     // FILTER output
     const uint32_t* thr;    // [nq] ordered keys
     int32_t* cnt;           // [nq]
@@ -441,12 +443,25 @@ __global__ __launch_bounds__(SCAN_THREADS) void knn_scan_kernel(const ScanArgs a
             if (a.probe_mask)
                 cand = cand && cid_ok && ((s_mask[ql * 8 + (cid >> 5)] >> (cid & 31)) & 1u);
             if (MODE == MODE_DENSE) {
+                const float sc = cand ? comb : -INFINITY;
                 if (q < a.nq)
-                    a.dense[(int64_t)q * a.dense_ld + (int64_t)blockIdx.x * BR + lrow] =
-                        cand ? comb : -INFINITY;
+                    a.dense[(int64_t)q * a.dense_ld + (int64_t)blockIdx.x * BR + lrow] = sc;
+                acc[r][e] = sc;
             } else {
                 acc[r][e] = comb;
                 if (cand && ord_key(comb) >= thr[e]) pass |= 1ull << (r * 16 + e);
+            }
+        }
+        if (MODE == MODE_DENSE && a.gmax) {
+            // max over the 32 rows (lanes li) of this 32-row group, per query
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float m = acc[r][e];
+#pragma unroll
+                for (int off = 16; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+                const int q = q0 + wq * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (li == 0 && q < a.nq)
+                    a.gmax[(int64_t)q * a.gmax_ld + (int64_t)blockIdx.x * (BR / 32) + wr * RT + r] = m;
             }
         }
     }
@@ -824,6 +839,82 @@ __global__ __launch_bounds__(256) void kmeans_update_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------------------------------
+// Sample threshold.  The k-th largest of the per-group maxima of the sample (groups = 32-row
+// tiles) is a valid lower bound of the global k-th best score: the k largest group maxima are k
+// distinct rows scoring at least that much.  One workgroup per query:
+//   1. rank-count the G group maxima in LDS -> thr[q];
+//   2. append every sample entry that reaches thr to the query's candidate list and publish the
+//      count (so the counters and thresholds need no memset).
+// ------------------------------------------------------------------------------------------
+constexpr int THR_MAX_GROUPS = 4096;
+
+__global__ __launch_bounds__(256) void sample_threshold_kernel(
+    const float* __restrict__ gmax, int64_t gmax_ld, int G, const float* __restrict__ dense,
+    int64_t dense_ld, int64_t cols, int blk, int step, int64_t row_begin, int64_t row_end, int k,
+    uint32_t* __restrict__ thr_out, int32_t* __restrict__ cnt_out, float* __restrict__ cand_scores,
+    int32_t* __restrict__ cand_idx, int cap) {
+    __shared__ uint32_t s_g[THR_MAX_GROUPS];
+    __shared__ uint32_t s_thr;
+    __shared__ int s_cnt;
+    const int q = blockIdx.x, tid = threadIdx.x;
+    for (int g = tid; g < G; g += 256) s_g[g] = ord_key(gmax[(int64_t)q * gmax_ld + g]);
+    if (tid == 0) { s_thr = 0u; s_cnt = 0; }
+    __syncthreads();
+    if (G >= k) {
+        for (int g = tid; g < G; g += 256) {
+            const uint32_t mine = s_g[g];
+            int rank = 0;   // number of groups ordered before this one (ties -> lower group first)
+            for (int j = 0; j < G; ++j) {
+                const uint32_t o = s_g[j];
+                rank += (o > mine || (o == mine && j < g)) ? 1 : 0;
+            }
+            if (rank == k - 1) s_thr = mine;
+        }
+    }
+    __syncthreads();
+    const uint32_t thr = s_thr;
+    for (int64_t j = tid; j < cols; j += 256) {
+        const float sc = dense[(int64_t)q * dense_ld + j];
+        const int64_t row = row_begin + (j / blk) * (int64_t)blk * step + j % blk;
+        if (sc > -INFINITY && row < row_end && ord_key(sc) >= thr) {
+            const int p = atomicAdd(&s_cnt, 1);
+            if (p < cap) {
+                cand_scores[(int64_t)q * cap + p] = sc;
+                cand_idx[(int64_t)q * cap + p] = (int32_t)row;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        thr_out[q] = thr;
+        cnt_out[(int64_t)q * CNT_STRIDE] = s_cnt;
+    }
+}
+
+// inverse L2 norms of the queries (one wave per query) + reset of the overflow flag
+__global__ __launch_bounds__(256) void query_prep_kernel(const float* __restrict__ x,
+                                                         float* __restrict__ inv, int64_t n,
+                                                         int64_t D, int32_t* overflow) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (overflow && blockIdx.x == 0 && threadIdx.x == 0) *overflow = 0;
+    if (row >= n) return;
+    const float* p = x + row * D;
+    float s = 0.0f;
+    if ((D & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) & 15) == 0)) {
+        for (int64_t i = lane * 4; i < D; i += 256) {
+            float4 v = *reinterpret_cast<const float4*>(p + i);
+            s = fmaf(v.x, v.x, s); s = fmaf(v.y, v.y, s); s = fmaf(v.z, v.z, s); s = fmaf(v.w, v.w, s);
+        }
+    } else {
+        for (int64_t i = lane; i < D; i += 64) s = fmaf(p[i], p[i], s);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) inv[row] = 1.0f / fmaxf(sqrtf(s), 1e-12f);
+}
+
+// ------------------------------------------------------------------------------------------
 // Exact top-k select: one 256-thread workgroup per (chunk, query).  64-bit composite keys
 // (ord(score) << 32 | ~idx) make every key unique, so "k-th largest key" is exact and ties go
 // to the lower index.  MSB-first 8-bit radix select over LDS-resident keys, then the k winners
@@ -866,6 +957,7 @@ __global__ __launch_bounds__(SEL_THREADS) void topk_select_kernel(const SelectAr
     __shared__ unsigned long long s_win[SEL_MAX_K];
     __shared__ int s_nwin;
     __shared__ unsigned int s_wsum[SEL_THREADS / 64];
+    __shared__ int s_done;
 
     const int tid = threadIdx.x;
     const int q = blockIdx.y;
@@ -900,7 +992,7 @@ __global__ __launch_bounds__(SEL_THREADS) void topk_select_kernel(const SelectAr
         s_keys[i] = ((unsigned long long)ord_key(s) << 32) | (0xffffffffu - (uint32_t)idx);
     }
     const int k = a.k < n ? a.k : n;  // winners available in this chunk
-    if (tid == 0) { s_prefix = 0ull; s_remaining = k; s_nwin = 0; }
+    if (tid == 0) { s_prefix = 0ull; s_remaining = k; s_nwin = 0; s_done = 0; }
     __syncthreads();
 
     if (k > 0 && k < n) {
@@ -951,8 +1043,12 @@ __global__ __launch_bounds__(SEL_THREADS) void topk_select_kernel(const SelectAr
             if ((int)x >= rem && (int)(x - h) < rem) {
                 s_prefix = prefix | ((unsigned long long)tid << shift);
                 s_remaining = rem - (int)(x - h);
+                // after the last score byte: if every key sharing this score is needed, the index
+                // bytes cannot change the answer -> take all keys >= (score << 32)
+                s_done = (byte == 4 && (int)h == rem - (int)(x - h)) ? 1 : 0;
             }
             __syncthreads();
+            if (s_done) break;
         }
     }
     const unsigned long long kth = (k > 0 && k < n) ? s_prefix : 0ull;
@@ -1046,6 +1142,7 @@ struct Workspace {
     float* cand2_scores; // [qb][cap2]  (reduce ping-pong)
     int32_t* cand2_idx;
     float* dense;        // [qb][dense cols]
+    float* gmax;         // [qb][THR_MAX_GROUPS]
     int cap, cap2;
     int64_t bytes;
 };
@@ -1079,6 +1176,7 @@ inline Workspace carve(void* base, int64_t N, int64_t nq, int k) {
     w.cand2_idx = reinterpret_cast<int32_t*>(take((int64_t)qb * w.cap2 * 4));
     const int64_t cols = N < DENSE_COLS ? align_up(N > 0 ? N : 1, 1024) : DENSE_COLS;
     w.dense = reinterpret_cast<float*>(take((int64_t)qb * cols * 4));
+    w.gmax = reinterpret_cast<float*>(take((int64_t)qb * THR_MAX_GROUPS * 4));
     w.bytes = off;
     return w;
 }
@@ -1257,7 +1355,6 @@ int aura_knn_search_ex(const float* bank, const float* inv_norm, const float* me
     if (w.bytes > workspace_bytes) return AURA_E_INVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     int rc;
-    if (overflow_out && hipMemsetAsync(overflow_out, 0, 4, s) != hipSuccess) return AURA_E_LAUNCH;
 
     for (int64_t qb0 = 0; qb0 < nq; qb0 += QBLOCK) {
         const int nqb = (int)((nq - qb0) < QBLOCK ? (nq - qb0) : QBLOCK);
@@ -1265,11 +1362,9 @@ int aura_knn_search_ex(const float* bank, const float* inv_norm, const float* me
         const int br = tile_rows_for(nqb);
         const int64_t ntiles = (N + br - 1) / br;
 
-        hipLaunchKernelGGL(row_inv_norm_kernel, dim3((unsigned)((nqb + 3) / 4)), dim3(256), 0, s,
-                           qptr, w.inv_q, (int64_t)nqb, D);
+        hipLaunchKernelGGL(query_prep_kernel, dim3((unsigned)((nqb + 3) / 4)), dim3(256), 0, s,
+                           qptr, w.inv_q, (int64_t)nqb, D, qb0 == 0 ? overflow_out : nullptr);
         if ((rc = check_launch())) return rc;
-        if (hipMemsetAsync(w.cnt, 0, QBLOCK * CNT_STRIDE * 4, s) != hipSuccess) return AURA_E_LAUNCH;
-        if (hipMemsetAsync(w.thr, 0, QBLOCK * 4, s) != hipSuccess) return AURA_E_LAUNCH;
 
         ScanArgs a{};
         a.bank = bank; a.inv_norm = inv_norm; a.meta = meta; a.loc = loc;
@@ -1299,10 +1394,12 @@ int aura_knn_search_ex(const float* bank, const float* inv_norm, const float* me
         if (sample_rows < 8192) sample_rows = 8192;
         const int64_t n_sample_tiles = (sample_rows + br - 1) / br;
         const bool dense_all = (flags & AURA_KNN_FORCE_DENSE) || n_sample_tiles * 4 > ntiles ||
-                               n_sample_tiles * br > DENSE_COLS;
+                               n_sample_tiles * br > DENSE_COLS ||
+                               n_sample_tiles * br / 32 > THR_MAX_GROUPS || n_sample_tiles * br / 32 < k;
         int64_t cur_n;  // candidate slots in use (capacity view) after this stage
         const int32_t* cur_cnt;
         if (dense_all) {
+            if (hipMemsetAsync(w.cnt, 0, QBLOCK * CNT_STRIDE * 4, s) != hipSuccess) return AURA_E_LAUNCH;
             const int64_t tiles_per_super = DENSE_COLS / br;
             int64_t appended = 0;
             for (int64_t t0 = 0; t0 < ntiles; t0 += tiles_per_super) {
@@ -1326,6 +1423,7 @@ int aura_knn_search_ex(const float* bank, const float* inv_norm, const float* me
             const int64_t cols = n_sample_tiles * br;
             a.tile_step = tile_step; a.n_sample_tiles = (int)n_sample_tiles; a.dense_ld = cols;
             a.logical_rows = br;
+            a.gmax = w.gmax; a.gmax_ld = THR_MAX_GROUPS;
             if (nqb > 128) {
                 // 32-row kernel tiles: 4x the workgroups of the 128-row geometry, so the short
                 // sample pass covers the whole chip instead of a few CUs
@@ -1333,10 +1431,13 @@ int aura_knn_search_ex(const float* bank, const float* inv_norm, const float* me
             } else {
                 if ((rc = dispatch_scan(a, MODE_DENSE, n_sample_tiles, s))) return rc;
             }
-            const int64_t nchunks = (cols + SEL_CHUNK - 1) / SEL_CHUNK;
-            sel.src_qs = cols; sel.src_inner = cols; sel.n_max = cols; sel.step = tile_step;
-            sel.row_begin = 0; sel.dst_off = 0; sel.thr_out = w.thr;
-            if ((rc = launch_select(sel, nchunks, nqb, s))) return rc;
+            a.gmax = nullptr;
+            // threshold = k-th largest group maximum; sample entries that reach it seed the lists
+            hipLaunchKernelGGL(sample_threshold_kernel, dim3((unsigned)nqb), dim3(256), 0, s, w.gmax,
+                               (int64_t)THR_MAX_GROUPS, (int)(cols / 32), w.dense, cols, cols, br,
+                               tile_step, (int64_t)0, N, k, w.thr, w.cnt, w.cand_scores, w.cand_idx,
+                               w.cap);
+            if ((rc = check_launch())) return rc;
             // 2) main scan appends the rows that reach the bound (sample tiles are skipped)
             const bool prof = g_prof.on && g_prof.used < g_prof.cap;
             if (prof) (void)hipEventRecord(g_prof.start[g_prof.used], s);

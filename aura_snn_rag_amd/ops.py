@@ -179,6 +179,7 @@ def bank_decay(meta, rate: float, count: int) -> None:
 
 
 _workspaces = {}
+_ovf_flags = {}
 
 
 def _workspace(device, nbytes: int) -> torch.Tensor:
@@ -232,7 +233,9 @@ def knn_search(bank, inv_norm, meta, queries, k: int, now: float, count: Optiona
         raise _lib.AuraHipError("aura_knn_workspace_bytes failed")
     ws = _workspace(dev, nbytes)
     base = (ws.data_ptr() + 255) // 256 * 256
-    ovf = torch.zeros(1, dtype=torch.int32, device=dev)
+    ovf = _ovf_flags.get(dev)          # reset by the library's prep kernel on every call
+    if ovf is None:
+        ovf = _ovf_flags[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
 
     def run(flags):
         check(L.aura_knn_search_ex(_p(bank), _p(inv_norm), _p(meta), _p(loc), sd, _p(queries),
