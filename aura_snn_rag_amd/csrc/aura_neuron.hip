@@ -17,6 +17,7 @@
 // pragma below; division and exp are the correctly rounded / OCML forms.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/aura_hip.h"
 
@@ -359,6 +360,91 @@ __global__ __launch_bounds__(64 * NT_WAVES) void seq_nt_kernel(Model m, const fl
 }
 
 // ------------------------------------------------------------------------------------------
+// Time-contiguous kernel, wave-tile form (T % 4 == 0): ONE WAVE = 64 neurons x W timesteps with
+// W = T for T <= 128 (else 128-step chunks).  For W = T the wave's input is one contiguous
+// 64*T*4-byte region of HBM, so every load/store instruction moves 1 KiB of consecutive bytes and
+// each cache line is fetched exactly once (the 32-step tiling above re-fetches the lines that a
+// 400-byte row shares between chunks: FETCH_SIZE showed 2.1x the algorithmic bytes at T = 100).
+// LDS row stride S = W rounded so that S/4 is odd: the per-lane ds_read_b128 of 64 different rows
+// then hits 16 distinct 16-byte slots per lane group (conflict free).  Blocks are single waves,
+// so no workgroup barrier is needed; 4-6 independent waves per CU overlap their load / compute /
+// store phases.
+// ------------------------------------------------------------------------------------------
+constexpr int NTW_MAXW = 128;
+
+template <class Model>
+__global__ __launch_bounds__(64) void seq_ntw_kernel(Model m, const float* __restrict__ I,
+                                                     float* __restrict__ Sp, float* st0, float* st1,
+                                                     int64_t N, int64_t Tn, int Wmax, int S) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];  // [64][S]
+    const int lane = threadIdx.x;
+    const int64_t n0 = (int64_t)blockIdx.x * 64;
+    const int64_t n = n0 + lane;
+    const int nrows = (N - n0) < 64 ? (int)(N - n0) : 64;
+
+    typename Model::Lane ln;
+    m.init(ln, n);
+    ln.s0 = 0.0f;
+    ln.s1 = 0.0f;
+    if (n < N) {
+        ln.s0 = st0[n];
+        if (Model::NS > 1) ln.s1 = st1[n];
+    }
+    float* myrow = tile + lane * S;
+
+    for (int64_t t0 = 0; t0 < Tn; t0 += Wmax) {
+        const int W = (Tn - t0) < Wmax ? (int)(Tn - t0) : Wmax;  // multiple of 4
+        const int w4 = W >> 2;                                   // float4 per row piece = pieces
+        // (row, col4) of this lane's element in piece p: e4 = p*64 + lane; advance incrementally
+        const int dq = 64 / w4, dr = 64 % w4;
+        int row = lane / w4, c4 = lane % w4;
+        // ---- load: pieces in batches of 8 (32 VGPRs in flight per lane; issuing all 25-32
+        //      pieces at once costs 256 VGPRs and measured slower)
+        for (int p0 = 0; p0 < w4; p0 += 8) {
+            float4 v[8];
+            int ra[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                ra[j] = row * S + 4 * c4;
+                v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p0 + j < w4 && row < nrows)
+                    v[j] = *reinterpret_cast<const float4*>(I + (n0 + row) * Tn + t0 + 4 * c4);
+                row += dq; c4 += dr;
+                if (c4 >= w4) { c4 -= w4; ++row; }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (p0 + j < w4) *reinterpret_cast<float4*>(tile + ra[j]) = v[j];
+        }
+        __syncthreads();   // single-wave block: orders the LDS writes before the row reads
+        // ---- compute: this lane's neuron over W steps, spikes written back in place
+        for (int j = 0; j < w4; ++j) {
+            float xin[4], spk[4];
+            Io<float, 4>::load(myrow + 4 * j, xin);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) spk[e] = m.step(ln, xin[e]);
+            Io<float, 4>::store(myrow + 4 * j, spk);
+        }
+        __syncthreads();
+        // ---- store: mirror of the load
+        row = lane / w4; c4 = lane % w4;
+        for (int p = 0; p < w4; ++p) {
+            if (row < nrows) {
+                const float4 v = *reinterpret_cast<const float4*>(tile + row * S + 4 * c4);
+                *reinterpret_cast<float4*>(Sp + (n0 + row) * Tn + t0 + 4 * c4) = v;
+            }
+            row += dq; c4 += dr;
+            if (c4 >= w4) { c4 -= w4; ++row; }
+        }
+        __syncthreads();
+    }
+    if (n < N) {
+        st0[n] = ln.s0;
+        if (Model::NS > 1) st1[n] = ln.s1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Host-side launch helpers
 // ------------------------------------------------------------------------------------------
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -382,7 +468,19 @@ int launch_nt(const Model& m, const float* I, float* S, float* st0, float* st1, 
     const int64_t blocks = (N + 64 * NT_WAVES - 1) / (64 * NT_WAVES);
     if (blocks > 0x7fffffffLL) return AURA_E_INVAL;
     const bool vec = (T % 4 == 0) && aligned16(I) && aligned16(S);
-    if (vec)
+    static const bool legacy = getenv("AURA_NT_LEGACY") != nullptr;
+    // rows that are whole 128-byte lines (T % 32 == 0) stream best through the 32-step tiling
+    // (5.3 TB/s at T = 128 vs 3.6 for the wave-tile form); other T re-fetch split lines there
+    // (2.9 TB/s at T = 100) and use the contiguous wave-tile form (4.4 TB/s)
+    if (vec && !legacy && (T % 32 != 0)) {
+        // wave-tile form: W = T if T <= 128, else 128-step chunks; stride with S/4 odd
+        const int W = T <= NTW_MAXW ? (int)T : NTW_MAXW;
+        const int Sld = ((W / 4) & 1) ? W : W + 4;
+        const int64_t wblocks = (N + 63) / 64;
+        if (wblocks > 0x7fffffffLL) return AURA_E_INVAL;
+        hipLaunchKernelGGL((seq_ntw_kernel<Model>), dim3((unsigned)wblocks), dim3(64),
+                           (size_t)64 * Sld * sizeof(float), s, m, I, S, st0, st1, N, T, W, Sld);
+    } else if (vec)
         hipLaunchKernelGGL((seq_nt_kernel<Model, 4>), dim3((unsigned)blocks), dim3(64 * NT_WAVES),
                            0, s, m, I, S, st0, st1, N, T);
     else
