@@ -47,6 +47,7 @@ SIGNATURES = {
     "aura_addition_linear": (I, [P, P, P, P, I64, I64, I64, P]),
     "aura_profile_begin": (I, [I]),
     "aura_profile_end": (I, [P, I]),
+    "aura_profile_last_scan": (I, [P, P]),
 }
 
 

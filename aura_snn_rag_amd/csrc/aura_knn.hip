@@ -1204,6 +1204,7 @@ struct ProfileState {
     hipEvent_t* stop = nullptr;
     int cap = 0, used = 0;
     bool on = false;
+    int64_t rows = 0, nq = 0;   // rows x queries scored by the last profiled main-scan launch
 };
 ProfileState g_prof;
 
@@ -1440,7 +1441,11 @@ int aura_knn_search_ex(const float* bank, const float* inv_norm, const float* me
             if ((rc = check_launch())) return rc;
             // 2) main scan appends the rows that reach the bound (sample tiles are skipped)
             const bool prof = g_prof.on && g_prof.used < g_prof.cap;
-            if (prof) (void)hipEventRecord(g_prof.start[g_prof.used], s);
+            if (prof) {
+                (void)hipEventRecord(g_prof.start[g_prof.used], s);
+                g_prof.rows = N - n_sample_tiles * br;
+                g_prof.nq = nqb;
+            }
             static const bool force_v1 = getenv("AURA_SCAN_V1") != nullptr;
             if (nqb > 128 && !force_v1) {
                 a.n_items = (N + 31) / 32 - 4 * n_sample_tiles;
@@ -1580,6 +1585,13 @@ int aura_profile_end(float* ms_out_host, int max_out) {
         ms_out_host[i] = ms;
     }
     return n;
+}
+
+int aura_profile_last_scan(int64_t* rows_out, int64_t* nq_out) {
+    if (!rows_out || !nq_out) return AURA_E_INVAL;
+    *rows_out = g_prof.rows;
+    *nq_out = g_prof.nq;
+    return AURA_OK;
 }
 
 }  // extern "C"

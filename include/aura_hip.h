@@ -146,6 +146,9 @@ int aura_knn_search_ex(const float* bank, const float* inv_norm, const float* me
  * (negative AURA_E_* on error). */
 int aura_profile_begin(int max_launches);
 int aura_profile_end(float* ms_out_host, int max_out);
+/* Bank rows and queries scored by the most recent profiled main-scan launch (HOST pointers):
+ * the units behind bench.py's algorithmic FLOP count, 2 * rows * nq * D per launch. */
+int aura_profile_last_scan(int64_t* rows_out, int64_t* nq_out);
 
 /* Merge S per-shard top-k lists into the global top-k (the step after the RCCL all-gather,
  * SURVEY.md section 8e).  in_scores/in_idx: [S][nq][k]; out: [nq][k]; ties -> lower index. */
