@@ -516,7 +516,9 @@ __device__ __forceinline__ int64_t filter_tile_of(int64_t j, int step, int ns) {
     return (int64_t)ns * s + (j - (int64_t)ns * per);
 }
 
-template <bool VEC4>
+// FAST = no location term and no centroid mask (the common case): those branches and their
+// registers are compiled out of the epilogue.
+template <bool VEC4, bool FAST>
 __global__ __launch_bounds__(SCAN_THREADS) void knn_scan_filter_v2(const ScanArgs a) {
     constexpr int BQ = 256, BRR = 128, RT = 4;
     constexpr int TILE_FLOATS = (BQ + BRR) * LDS_STRIDE;
@@ -641,7 +643,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void knn_scan_filter_v2(const ScanArg
 
         // ---- epilogue: combined score + candidate append (same arithmetic as knn_scan_kernel) ----
         uint32_t* s_mask = reinterpret_cast<uint32_t*>(smem);
-        if (a.probe_mask) {
+        if (!FAST && a.probe_mask) {
             for (int t = tid; t < BQ * 8; t += SCAN_THREADS) {
                 const int q = t >> 3;
                 s_mask[t] = q < a.nq ? a.probe_mask[(int64_t)q * 8 + (t & 7)] : 0u;
@@ -649,13 +651,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void knn_scan_filter_v2(const ScanArg
             __syncthreads();
         }
         // per-lane query constants: re-read per chunk (L2 hits) rather than held in 32 VGPRs
-        float iq[16];
-        uint32_t thr[16];
+        float iq[16], thrf[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int q = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
             iq[e] = q < a.nq ? a.inv_q[q] : 0.0f;
-            thr[e] = q < a.nq ? a.thr[q] : 0xffffffffu;
+            thrf[e] = q < a.nq ? ord_unkey(a.thr[q]) : INFINITY;   // same order as the key compare
         }
         unsigned long long pass = 0ull;
 #pragma unroll
@@ -672,29 +673,42 @@ __global__ __launch_bounds__(SCAN_THREADS) void knn_scan_filter_v2(const ScanArg
                 const float age = a.now - m.y;
                 tw = 0.2f * expf(-age / 3600.0f);
                 cid = (int)m.z;
-                if (a.q_loc)
+                if (!FAST && a.q_loc)
                     for (int d = 0; d < a.sdims && d < 4; ++d) lx[d] = a.loc[row * a.sdims + d];
             }
-            const bool cid_ok = cid >= 0 && cid < 256;
+            if (FAST) {
+                unsigned int bits = 0u;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int q = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                const float sim = acc[r][e] * iq[e] * inv_m;
-                float comb = 0.5f * sim;
-                if (a.q_loc && q < a.nq) {
-                    float d2 = 0.0f;
-                    for (int d = 0; d < a.sdims && d < 4; ++d) {
-                        const float df = lx[d] - a.q_loc[(int64_t)q * a.sdims + d];
-                        d2 = d2 + df * df;
-                    }
-                    comb = comb + 0.3f * (1.0f / (1.0f + sqrtf(d2)));
+                for (int e = 0; e < 16; ++e) {
+                    const float sim = acc[r][e] * iq[e] * inv_m;
+                    const float comb = (0.5f * sim + tw) * strength;
+                    acc[r][e] = comb;
+                    bits |= (comb >= thrf[e]) ? (1u << e) : 0u;
                 }
-                comb = (comb + tw) * strength;
-                bool cand = vrow && q < a.nq;
-                if (a.probe_mask)
-                    cand = cand && cid_ok && ((s_mask[q * 8 + (cid >> 5)] >> (cid & 31)) & 1u);
-                acc[r][e] = comb;
-                if (cand && ord_key(comb) >= thr[e]) pass |= 1ull << (r * 16 + e);
+                if (!vrow) bits = 0u;
+                pass |= (unsigned long long)bits << (r * 16);
+            } else {
+                const bool cid_ok = cid >= 0 && cid < 256;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int q = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    const float sim = acc[r][e] * iq[e] * inv_m;
+                    float comb = 0.5f * sim;
+                    if (a.q_loc && q < a.nq) {
+                        float d2 = 0.0f;
+                        for (int d = 0; d < a.sdims && d < 4; ++d) {
+                            const float df = lx[d] - a.q_loc[(int64_t)q * a.sdims + d];
+                            d2 = d2 + df * df;
+                        }
+                        comb = comb + 0.3f * (1.0f / (1.0f + sqrtf(d2)));
+                    }
+                    comb = (comb + tw) * strength;
+                    bool cand = vrow && q < a.nq;
+                    if (a.probe_mask)
+                        cand = cand && cid_ok && ((s_mask[q * 8 + (cid >> 5)] >> (cid & 31)) & 1u);
+                    acc[r][e] = comb;
+                    if (cand && comb >= thrf[e]) pass |= 1ull << (r * 16 + e);
+                }
             }
         }
         if (pass != 0ull) {
@@ -723,7 +737,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void knn_scan_filter_v2(const ScanArg
                 }
             }
         }
-        if (a.probe_mask) __syncthreads();   // s_mask aliases the staging buffers
+        if (!FAST && a.probe_mask) __syncthreads();   // s_mask aliases the staging buffers
     }
 }
 
@@ -873,9 +887,11 @@ __global__ __launch_bounds__(256) void sample_threshold_kernel(
     }
     __syncthreads();
     const uint32_t thr = s_thr;
+    const int blk_log2 = 31 - __clz(blk);
     for (int64_t j = tid; j < cols; j += 256) {
         const float sc = dense[(int64_t)q * dense_ld + j];
-        const int64_t row = row_begin + (j / blk) * (int64_t)blk * step + j % blk;
+        const int jj = (int)j;   // cols <= 131072; blk is a power of two (128 or 256)
+        const int64_t row = row_begin + (int64_t)(jj >> blk_log2) * blk * step + (jj & (blk - 1));
         if (sc > -INFINITY && row < row_end && ord_key(sc) >= thr) {
             const int p = atomicAdd(&s_cnt, 1);
             if (p < cap) {
@@ -1249,11 +1265,13 @@ inline int launch_filter_v2(const ScanArgs& a, hipStream_t s) {
     const size_t lds = (size_t)2 * (256 + 128) * LDS_STRIDE * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(knn_scan_filter_v2<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(knn_scan_filter_v2<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return AURA_E_LAUNCH;
+        const void* fns[4] = {reinterpret_cast<const void*>(knn_scan_filter_v2<true, true>),
+                              reinterpret_cast<const void*>(knn_scan_filter_v2<true, false>),
+                              reinterpret_cast<const void*>(knn_scan_filter_v2<false, true>),
+                              reinterpret_cast<const void*>(knn_scan_filter_v2<false, false>)};
+        for (const void* f : fns)
+            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return AURA_E_LAUNCH;
         attr_set = true;
     }
     if (a.n_items <= 0) return AURA_OK;
@@ -1262,10 +1280,12 @@ inline int launch_filter_v2(const ScanArgs& a, hipStream_t s) {
     if (grid > chunks) grid = chunks;
     const bool vec4 = (a.D % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.bank) & 15) == 0) &&
                       ((reinterpret_cast<uintptr_t>(a.queries) & 15) == 0);
-    if (vec4)
-        hipLaunchKernelGGL(knn_scan_filter_v2<true>, dim3((unsigned)grid), dim3(SCAN_THREADS), lds, s, a);
-    else
-        hipLaunchKernelGGL(knn_scan_filter_v2<false>, dim3((unsigned)grid), dim3(SCAN_THREADS), lds, s, a);
+    const bool fast = !a.q_loc && !a.probe_mask;
+    const dim3 g((unsigned)grid), b(SCAN_THREADS);
+    if (vec4 && fast) hipLaunchKernelGGL((knn_scan_filter_v2<true, true>), g, b, lds, s, a);
+    else if (vec4) hipLaunchKernelGGL((knn_scan_filter_v2<true, false>), g, b, lds, s, a);
+    else if (fast) hipLaunchKernelGGL((knn_scan_filter_v2<false, true>), g, b, lds, s, a);
+    else hipLaunchKernelGGL((knn_scan_filter_v2<false, false>), g, b, lds, s, a);
     return check_launch();
 }
 
