@@ -56,7 +56,7 @@ class ShardedRecall:
                ) -> Tuple[torch.Tensor, torch.Tensor]:
         S = self.world
         nq = queries.shape[0]
-        if S == 1:
+        if not dist.is_initialized():
             s, r = self.local_search(queries, k)
             return self.merge(s.unsqueeze(0), r.unsqueeze(0), k)
         if all_gather_queries:
@@ -66,12 +66,14 @@ class ShardedRecall:
             allq = queries
         s, r = self.local_search(allq, k)                       # [n, k] over this shard
         n = allq.shape[0]
-        # flat [S*n, k] outputs (concatenation along dim 0 is the layout both RCCL and gloo accept)
-        gs = torch.empty(S * n, k, dtype=s.dtype, device=s.device)
-        gr = torch.empty(S * n, k, dtype=r.dtype, device=r.device)
-        dist.all_gather_into_tensor(gs, s.contiguous(), group=self.group)
-        dist.all_gather_into_tensor(gr, r.contiguous(), group=self.group)
-        gs, gr = gs.view(S, n, k), gr.view(S, n, k)
+        # ONE collective for scores and rows: fp32 scores travel bit-cast to int32 beside the int32
+        # rows as a flat [S*2*n, k] tensor (concatenation along dim 0 is the layout both RCCL
+        # and gloo accept); nq*k*8 bytes per rank, latency bound
+        packed = torch.cat([s.contiguous().view(torch.int32), r.contiguous()], dim=0)   # [2n, k]
+        g = torch.empty(S * 2 * n, k, dtype=torch.int32, device=s.device)
+        dist.all_gather_into_tensor(g, packed, group=self.group)
+        g = g.view(S, 2, n, k)
+        gs, gr = g[:, 0].contiguous().view(torch.float32), g[:, 1].contiguous()
         if all_gather_queries:                                   # keep only this rank's queries
             lo = self.rank * nq
             gs = gs[:, lo:lo + nq].contiguous()

@@ -158,8 +158,11 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    use_dist = world > 1 or os.environ.get("AURA_BENCH_FORCE_DIST") == "1"   # 1-rank RCCL smoke test
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from aura_snn_rag_amd import _lib, ops
     from aura_snn_rag_amd.sharded import ShardedRecall, shard_rows
@@ -185,19 +188,19 @@ def main():
     recall = ShardedRecall(local_search, ops.topk_merge)
 
     def step(check=False):
-        if world == 1:
+        if not use_dist:
             return local_search(q, k, check)
         return recall.recall(q, k, all_gather_queries=True)
 
     # correctness guard before timing: overflow check + planted neighbours found
-    s, i = step(check=True) if world == 1 else step()
+    s, i = step(check=True) if not use_dist else step()
     torch.cuda.synchronize()
     planted_ok = bool((i[: nq // 2, 0].cpu() == (pick + r0).to(torch.int32)).float().mean() > 0.99)
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     lib.aura_profile_begin(max(1, args.steps * 4))
     torch.cuda.synchronize()
@@ -205,12 +208,12 @@ def main():
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     buf = (ctypes.c_float * (args.steps * 4))()
     nprof = lib.aura_profile_end(buf, args.steps * 4)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -270,7 +273,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(args.bank_rows, D, k, args.cpu_queries)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
