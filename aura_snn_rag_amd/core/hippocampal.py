@@ -95,6 +95,8 @@ class HippocampalFormation(nn.Module):
         self.episodic_memories: Dict[str, EpisodicMemory] = {}
         self.id_to_idx: Dict[str, int] = {}
         self._idx_to_id: List[Optional[str]] = [None] * max_memories  # dense reverse map
+        # bulk-ingested rows get implicit ids "<prefix><n>" resolved on lookup: (slot0, slot1, prefix, n0)
+        self._implicit_ids: List[Tuple[int, int, str, int]] = []
 
         self.current_location = torch.zeros(spatial_dimensions, device=dev)
         self.last_event_time = time.time()
@@ -213,6 +215,42 @@ class HippocampalFormation(nn.Module):
             self.id_to_idx[mid] = slot
             self._idx_to_id[slot] = mid
 
+    def id_of_row(self, row: int) -> Optional[str]:
+        """Memory id stored at bank row ``row`` (explicit id, else the implicit bulk id)."""
+        mid = self._idx_to_id[row]
+        if mid is None:
+            for s0, s1, prefix, n0 in reversed(self._implicit_ids):
+                if s0 <= row < s1:
+                    return f"{prefix}{n0 + row - s0}"
+        return mid
+
+    def bulk_write(self, features: torch.Tensor, id_prefix: str = "bulk-", first_index: int = 0,
+                   rebuild: bool = True) -> int:
+        """Seeding path for very large ingests (BASELINE config 5): rows go to the bank through the
+        batched write kernel with NO per-row Python objects (ids are implicit,
+        ``f"{id_prefix}{first_index + i}"``, resolved by ``id_of_row``) and NO online centroid
+        update; with ``rebuild`` the centroid index is rebuilt once at the end.  This deliberately
+        departs from the reference's rebuild-every-512-inserts schedule, which is quadratic in the
+        bank size; use ``create_episodic_memories`` for reference-identical semantics.
+        Returns the number of rows written (stops at ``max_memories``)."""
+        feats = self._features_to_device(features)
+        n = min(feats.shape[0], self.max_memories - self.memory_count)
+        if n <= 0:
+            return 0
+        s0 = self.memory_count
+        slot_t = torch.arange(s0, s0 + n, dtype=torch.int64, device=self.device)
+        ops.bank_write(self.memory_features, self.memory_locations, self.memory_metadata,
+                       self._inv_norm, feats[:n].contiguous(), slot_t,
+                       self.current_location.to(device=self.device, dtype=torch.float32).contiguous(),
+                       time.time())
+        self.memory_count = s0 + n
+        if self._norms_valid_upto >= s0:
+            self._norms_valid_upto = s0 + n
+        self._implicit_ids.append((s0, s0 + n, id_prefix, first_index))
+        if rebuild and self.use_centroid_index and self.memory_count > self.centroids_k:
+            self.rebuild_centroids()
+        return n
+
     def create_episodic_memory(self, memory_id: str, event_id: str, features: torch.Tensor,
                                associated_experts: List[str] = None) -> None:
         """Store one memory (reference ``:195-243``).  ``event_id`` / ``associated_experts`` are
@@ -298,9 +336,43 @@ class HippocampalFormation(nn.Module):
         scores, rows = self.recall_batch(q, k=k, locations=location)
         out = []
         for s, r in zip(scores[0].tolist(), rows[0].tolist()):
-            if r >= 0 and self._idx_to_id[r] is not None:
-                out.append((self._idx_to_id[r], s))
+            mid = self.id_of_row(r) if r >= 0 else None
+            if mid is not None:
+                out.append((mid, s))
         return out
+
+    # ------------------------------------------------------------------ persistence
+    def bank_state(self) -> Dict[str, Any]:
+        """Host-side state the reference forgets to checkpoint (``memory_count``, index flag, id
+        maps live outside its ``state_dict``, so a reloaded bank reports 0 memories).  Save this
+        beside ``state_dict()``; the tensors themselves stay in the ``state_dict`` unchanged."""
+        n = self.memory_count
+        return {"memory_count": n, "index_ready": bool(self._index_ready),
+                "write_cursor": self._write_cursor, "centroids_k": self.centroids_k,
+                "centroids_update_interval": self.centroids_update_interval,
+                "ids_by_slot": list(self._idx_to_id[:n]),
+                "id_to_idx": dict(self.id_to_idx),
+                "implicit_ids": list(self._implicit_ids)}
+
+    def load_bank_state(self, state: Dict[str, Any]) -> None:
+        """Inverse of ``bank_state`` (call after ``load_state_dict``)."""
+        n = int(state["memory_count"])
+        if not (0 <= n <= self.max_memories):
+            raise ValueError(f"memory_count {n} does not fit a bank of {self.max_memories}")
+        self.memory_count = n
+        self._index_ready = bool(state.get("index_ready", False))
+        self._write_cursor = int(state.get("write_cursor", 0))
+        self.centroids_k = int(state.get("centroids_k", self.centroids_k))
+        self.centroids_update_interval = int(state.get("centroids_update_interval",
+                                                       self.centroids_update_interval))
+        self._idx_to_id = list(state["ids_by_slot"]) + [None] * (self.max_memories - n)
+        self.id_to_idx = dict(state.get("id_to_idx") or
+                              {mid: i for i, mid in enumerate(state["ids_by_slot"]) if mid is not None})
+        self._implicit_ids = [tuple(x) for x in state.get("implicit_ids", [])]
+        stamp = time.time()
+        self.episodic_memories = {mid: EpisodicMemory(memory_id=mid, feature_idx=i, timestamp=stamp)
+                                  for mid, i in self.id_to_idx.items()}
+        self._invalidate_norms()
 
     def gather_features(self, rows: torch.Tensor) -> torch.Tensor:
         """``memory_features[rows]`` for int32 rows of any shape (``-1`` -> zeros): the

@@ -115,6 +115,28 @@ def secondary_neurons(dev):
                        "algorithmic_bytes": bytes_alg,
                        "hbm_gbs": bytes_alg / (ms * 1e-3) / 1e9,
                        "hbm_frac_of_8TBs": bytes_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    del h, out, vv, th
+    # whole spiking FFN at config 3 (d=768, H=3072, S=512, T=16, L=8, bf16): T-deduplicated GEMMs
+    # (vendor library) + the two fused GIF loops; neuron-steps = rows * T * (H + D)
+    from aura_snn_rag_amd.core.language_zone.snn_ffn import SNNFFN
+    torch.manual_seed(0)
+    ffn = SNNFFN(768, 3072, num_timesteps=16, L=8).to(dev).to(torch.bfloat16).eval()
+    x = torch.randn(1, 512, 768, device=dev, dtype=torch.bfloat16)
+    ms = timed(lambda: ffn(x))
+    res["snnffn_config3_bf16"] = {"ms": ms, "neuron_timesteps_per_s": 512 * 16 * (3072 + 768) / (ms * 1e-3),
+                                  "note": "module forward incl. 4 GEMMs; reference CPU path measured 315 ms (BASELINE.md)"}
+    # one-shot write throughput (config 5 seeding path): rows of 768 fp32 into the bank
+    from aura_snn_rag_amd.core.hippocampal import HippocampalFormation
+    hf = HippocampalFormation(feature_dim=768, max_memories=1 << 20, n_place_cells=8, n_time_cells=4,
+                              n_grid_cells=4, device="cuda", use_centroid_index=False)
+    rows_w = 1 << 18
+    fw = torch.randn(rows_w, 768, device=dev)
+    def wr():
+        hf.memory_count = 0
+        hf.bulk_write(fw, rebuild=False)
+    ms = timed(wr, iters=5)
+    res["bulk_write"] = {"rows": rows_w, "dim": 768, "ms": ms, "rows_per_s": rows_w / (ms * 1e-3),
+                         "hbm_gbs": rows_w * 768 * 8 / (ms * 1e-3) / 1e9}
     return res
 
 

@@ -305,3 +305,30 @@ def test_candidate_path_clustered_vs_oracle(dev, monkeypatch):
     for j, qq in enumerate(qs):
         rows, sc = ob.recall(qq, 7, NOW)
         assert r[j].cpu().long().tolist() == rows.tolist()
+
+
+def test_memory_ops_match_reference_layer_loop(dev, monkeypatch):
+    """Batched retrieve_memories == the reference layer's per-row loop
+    (memory_augmented_layer.py:106-130) restated on the oracle bank."""
+    from aura_snn_rag_amd.core.language_zone import memory_ops
+    H, hf = _mk_hf(dev, D=32, M=1000, use_centroid_index=False)
+    monkeypatch.setattr(H.time, "time", lambda: NOW)
+    ob = O.OracleBank(1000, 32, use_centroid_index=False)
+    g = torch.Generator().manual_seed(21)
+    feats = torch.randn(400, 32, generator=g)
+    hf.create_episodic_memories([f"m{i}" for i in range(400)], feats)
+    for i in range(400):
+        ob.write(f"m{i}", feats[i], NOW)
+    query = feats[[3, 77, 250]] + 0.05 * torch.randn(3, 32, generator=g)
+    mf, ms = memory_ops.retrieve_memories(hf, query.to(dev), k=5)
+    ref_f = torch.zeros(3, 5, 32); ref_s = torch.zeros(3, 5)
+    for b in range(3):
+        for i, (mid, score) in enumerate(ob.recall_ids(query[b], 5, NOW)):
+            ref_f[b, i] = ob.features[ob.id_to_idx[mid]]; ref_s[b, i] = score
+    assert torch.equal(mf.cpu(), ref_f) and torch.allclose(ms.cpu(), ref_s, atol=1e-5)
+    before = hf.memory_count
+    memory_ops.store_memory(hf, torch.randn(4, 7, 32, device=dev))
+    assert hf.memory_count == before + 4
+    empty = H.HippocampalFormation(feature_dim=32, max_memories=8, n_place_cells=4, n_time_cells=3, n_grid_cells=3, device="cuda")
+    z, zs = memory_ops.retrieve_memories(empty, query.to(dev), k=5)
+    assert z.abs().sum() == 0 and zs.abs().sum() == 0

@@ -169,3 +169,35 @@ def test_processor_combines_zones_like_reference():
     w = _softmax64(np.array([0.7, 0.3]))
     assert torch.allclose(y, float(w[0]) * x + float(w[1]) * 3 * x, atol=1e-6)
     assert set(p._current_zone_activities) == {"a", "b"}
+
+
+def test_bank_state_roundtrip(hmod):
+    """memory_count / id maps survive a save-load cycle (the reference drops them)."""
+    hf = _hf(hmod, M=6, use_centroid_index=False)
+    feats = torch.randn(8, 16)
+    for i in range(8):                       # overflows: slot 0 is overwritten twice
+        hf.create_episodic_memory(f"m{i}", "e", feats[i])
+    sd, bs = hf.state_dict(), hf.bank_state()
+    hf2 = _hf(hmod, M=6, use_centroid_index=False)
+    hf2.load_state_dict(sd)
+    assert hf2.memory_count == 0             # what the reference gives you
+    hf2.load_bank_state(bs)
+    assert hf2.memory_count == 6 and hf2.id_to_idx == hf.id_to_idx
+    assert hf2.retrieve_similar_memories(feats[3], k=1)[0][0] == "m3"
+    assert hf2.retrieve_similar_memories(feats[7], k=1)[0][0] == "m7"
+    import pickle
+    assert pickle.loads(pickle.dumps(bs)) == bs
+
+
+def test_bulk_write_implicit_ids(hmod):
+    hf = _hf(hmod, M=100)
+    hf.centroids_k = 4
+    feats = torch.randn(60, 16)
+    hf.create_episodic_memory("first", "e", feats[0])
+    assert hf.bulk_write(feats[1:41], id_prefix="doc-", first_index=1000) == 40
+    assert hf.memory_count == 41 and hf._index_ready          # one rebuild at the end
+    assert hf.id_of_row(0) == "first" and hf.id_of_row(1) == "doc-1000" and hf.id_of_row(40) == "doc-1039"
+    hf.use_centroid_index = False
+    assert hf.retrieve_similar_memories(feats[17], k=1)[0][0] == "doc-1016"
+    assert hf.bulk_write(torch.randn(100, 16)) == 59           # clipped at max_memories
+    assert len(hf.id_to_idx) == 1                              # no per-row Python objects
