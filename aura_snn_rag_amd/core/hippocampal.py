@@ -108,6 +108,9 @@ class HippocampalFormation(nn.Module):
         self.register_buffer('centroids', torch.zeros(self.centroids_k, feature_dim, device=dev))
         self.register_buffer('centroid_counts', torch.zeros(self.centroids_k, device=dev))
         self._index_ready = False
+        # inverted lists (row ids grouped by centroid id), derived lazily from memory_metadata[:, 2]
+        self._lists = None            # (list_rows, list_off, list_len) or None
+        self._lists_count = -1        # memory_count the lists were built for
 
         if overflow not in ('reference', 'fifo'):
             raise ValueError("overflow must be 'reference' or 'fifo'")
@@ -118,6 +121,24 @@ class HippocampalFormation(nn.Module):
     # ------------------------------------------------------------------ plumbing
     def _invalidate_norms(self) -> None:
         self._norms_valid_upto = 0
+        self._lists = None
+
+    def _ensure_lists(self):
+        """Inverted lists for the IVF recall: row ids of [0, memory_count) sorted by centroid id
+        (rows with id < 0 first), list starts and lengths -- a stable sort + bincount on the
+        device, redone only after a write / rebuild changed the assignments."""
+        n = self.memory_count
+        if self._lists is None or self._lists_count != n:
+            cids = self.memory_metadata[:n, 2].to(torch.int32)
+            order = torch.sort(cids, stable=True).indices.to(torch.int32)
+            valid = cids >= 0
+            lens = torch.bincount(cids.clamp(min=0).long(), weights=valid.to(torch.float32),
+                                  minlength=256)[:256].to(torch.int32)
+            n_neg = (n - valid.sum()).to(torch.int32).reshape(1)
+            off = torch.cat([n_neg, n_neg + torch.cumsum(lens, 0).to(torch.int32)]).contiguous()
+            self._lists = (order.contiguous(), off, lens.contiguous())
+            self._lists_count = n
+        return self._lists
 
     def _apply(self, fn, *a, **k):  # keep self.device / current_location in step with .to()
         out = super()._apply(fn, *a, **k)
@@ -206,6 +227,7 @@ class HippocampalFormation(nn.Module):
                        centroid_counts=self.centroid_counts if online else None,
                        eff_k=eff_k if online else 0)
         self.memory_count, self._write_cursor = new_count, new_cursor
+        self._lists = None
         lo, hi = min(slots), max(slots)
         if self._norms_valid_upto >= lo:      # the kernel refreshed 1/||row|| of the written slots
             self._norms_valid_upto = max(self._norms_valid_upto, hi + 1)
@@ -244,6 +266,7 @@ class HippocampalFormation(nn.Module):
                        self.current_location.to(device=self.device, dtype=torch.float32).contiguous(),
                        time.time())
         self.memory_count = s0 + n
+        self._lists = None
         if self._norms_valid_upto >= s0:
             self._norms_valid_upto = s0 + n
         self._implicit_ids.append((s0, s0 + n, id_prefix, first_index))
@@ -311,9 +334,19 @@ class HippocampalFormation(nn.Module):
                   q_loc=q_loc, check_overflow=check_overflow)
         if not cand:
             return ops.knn_search(self.memory_features, self._inv_norm, self.memory_metadata, q, kk, now, **kw)
-        scores, rows = ops.knn_search(self.memory_features, self._inv_norm, self.memory_metadata, q, kk,
-                                      now, centroids=self.centroids,
-                                      nprobe=min(8, self.centroids_k), **kw)
+        nprobe = min(8, self.centroids_k)
+        scores = rows = None
+        if q_loc is None and self.centroids.shape[0] == 256:
+            # inverted-list form: every probed list is streamed once per batch
+            list_rows, list_off, list_len = self._ensure_lists()
+            scores, rows, ovf = ops.knn_search_ivf(self.memory_features, self._inv_norm,
+                                                   self.memory_metadata, q, kk, now, self.memory_count,
+                                                   self.centroids, nprobe, list_rows, list_off, list_len)
+            if check_overflow and int(ovf.item()) != 0:
+                scores = rows = None          # a query's lists exceed the slot capacity
+        if scores is None:
+            scores, rows = ops.knn_search(self.memory_features, self._inv_norm, self.memory_metadata,
+                                          q, kk, now, centroids=self.centroids, nprobe=nprobe, **kw)
         # a query whose probed centroids own no rows falls back to the full scan (ref :269-270)
         empty = (rows[:, 0] < 0)
         if bool(empty.any()):
@@ -410,3 +443,4 @@ class HippocampalFormation(nn.Module):
                           meta=self.memory_metadata, update_means=False)
         self.centroid_counts = counts
         self._index_ready = True
+        self._lists = None

@@ -743,33 +743,79 @@ __global__ __launch_bounds__(SCAN_THREADS) void knn_scan_filter_v2(const ScanArg
 
 // ------------------------------------------------------------------------------------------
 // Centroid probe: for each query the `nprobe` nearest (L2, unnormalised query) of the 256
-// centroid rows -> 256-bit mask.  hippocampal.py:261-262 (topk over ALL 256 buffer rows, also
-// the zero rows beyond centroids_k).  One workgroup per query, ties -> lower centroid.
+// centroid rows -> 256-bit mask (+ ids in distance order).  hippocampal.py:261-262: the topk runs
+// over ALL 256 buffer rows, also the zero rows beyond centroids_k.  Two kernels:
+//   centroid_dist_kernel : dist[q][c] = sqrt(sum_d (c_d - q_d)^2), 8 queries x 64 centroids per
+//                          workgroup, 32-deep k-chunks through LDS with register prefetch
+//   probe_select_kernel  : per query, nprobe rounds of a 256-wide argmin (ties -> lower centroid)
+// (The first version did the distances one wave per centroid row inside the per-query workgroup:
+// 252 us for 256 queries; this split takes ~20 us.)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void centroid_probe_kernel(const float* __restrict__ centroids,
-                                                             const float* __restrict__ queries,
-                                                             int64_t D, int nprobe,
-                                                             uint32_t* __restrict__ mask_out) {
-    __shared__ float s_d[256];
+constexpr int PD_Q = 8, PD_C = 64;
+
+__global__ __launch_bounds__(256) void centroid_dist_kernel(const float* __restrict__ centroids,
+                                                            const float* __restrict__ queries,
+                                                            int64_t D, int nq,
+                                                            float* __restrict__ dist) {
+    __shared__ __attribute__((aligned(16))) float Cs[PD_C * LDS_STRIDE];
+    __shared__ __attribute__((aligned(16))) float Qs[PD_Q * LDS_STRIDE];
+    const int tid = threadIdx.x;
+    const int c0 = blockIdx.x * PD_C, q0 = blockIdx.y * PD_Q;
+    const int cl = tid & 63, qs = (tid >> 6) * 2;      // this thread: centroid cl x queries qs, qs+1
+    // staging slots: centroid tile 64 rows x 8 float4 = 512 (2 per thread), query tile 8 x 8 = 64
+    const int r0 = tid >> 3, col = (tid & 7) * 4;
+    const bool vec = (D & 3) == 0;
+    auto ld = [&](const float* base, int64_t k0) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!base) return v;
+        const int64_t k = k0 + col;
+        if (vec) { if (k < D) v = *reinterpret_cast<const float4*>(base + k); }
+        else {
+            if (k + 0 < D) v.x = base[k + 0];
+            if (k + 1 < D) v.y = base[k + 1];
+            if (k + 2 < D) v.z = base[k + 2];
+            if (k + 3 < D) v.w = base[k + 3];
+        }
+        return v;
+    };
+    const float* cb0 = centroids + (int64_t)(c0 + r0) * D;
+    const float* cb1 = centroids + (int64_t)(c0 + r0 + 32) * D;
+    const float* qb = (tid < 64 && q0 + r0 < nq) ? queries + (int64_t)(q0 + r0) * D : nullptr;
+    float4 p0 = ld(cb0, 0), p1 = ld(cb1, 0), p2 = ld(qb, 0);
+    float acc0 = 0.0f, acc1 = 0.0f;
+    for (int64_t k0 = 0; k0 < D; k0 += BK) {
+        *reinterpret_cast<float4*>(Cs + r0 * LDS_STRIDE + col) = p0;
+        *reinterpret_cast<float4*>(Cs + (r0 + 32) * LDS_STRIDE + col) = p1;
+        if (tid < 64) *reinterpret_cast<float4*>(Qs + r0 * LDS_STRIDE + col) = p2;
+        __syncthreads();
+        if (k0 + BK < D) { p0 = ld(cb0, k0 + BK); p1 = ld(cb1, k0 + BK); p2 = ld(qb, k0 + BK); }
+#pragma unroll
+        for (int j = 0; j < BK / 4; ++j) {
+            const float4 c = *reinterpret_cast<const float4*>(Cs + cl * LDS_STRIDE + 4 * j);
+            const float4 a = *reinterpret_cast<const float4*>(Qs + qs * LDS_STRIDE + 4 * j);
+            const float4 b = *reinterpret_cast<const float4*>(Qs + (qs + 1) * LDS_STRIDE + 4 * j);
+            float d;
+            d = c.x - a.x; acc0 = fmaf(d, d, acc0);  d = c.y - a.y; acc0 = fmaf(d, d, acc0);
+            d = c.z - a.z; acc0 = fmaf(d, d, acc0);  d = c.w - a.w; acc0 = fmaf(d, d, acc0);
+            d = c.x - b.x; acc1 = fmaf(d, d, acc1);  d = c.y - b.y; acc1 = fmaf(d, d, acc1);
+            d = c.z - b.z; acc1 = fmaf(d, d, acc1);  d = c.w - b.w; acc1 = fmaf(d, d, acc1);
+        }
+        __syncthreads();
+    }
+    if (q0 + qs < nq) dist[(int64_t)(q0 + qs) * 256 + c0 + cl] = sqrtf(acc0);
+    if (q0 + qs + 1 < nq) dist[(int64_t)(q0 + qs + 1) * 256 + c0 + cl] = sqrtf(acc1);
+}
+
+__global__ __launch_bounds__(256) void probe_select_kernel(const float* __restrict__ dist, int nprobe,
+                                                           uint32_t* __restrict__ mask_out,
+                                                           int32_t* __restrict__ ids_out) {
     __shared__ float s_bv[4];
     __shared__ int s_bi[4];
     __shared__ uint32_t s_m[8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float* q = queries + (int64_t)blockIdx.x * D;
-    for (int c = wave; c < 256; c += 4) {
-        const float* cp = centroids + (int64_t)c * D;
-        float acc = 0.0f;
-        for (int64_t j = lane; j < D; j += 64) {
-            const float d = cp[j] - q[j];
-            acc = fmaf(d, d, acc);
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
-        if (lane == 0) s_d[c] = sqrtf(acc);
-    }
+    float mine = dist[(int64_t)blockIdx.x * 256 + tid];
     if (tid < 8) s_m[tid] = 0u;
     __syncthreads();
-    float mine = s_d[tid];
     for (int p = 0; p < nprobe; ++p) {
         float bv = mine;
         int bi = tid;
@@ -785,10 +831,224 @@ __global__ __launch_bounds__(256) void centroid_probe_kernel(const float* __rest
 #pragma unroll
         for (int w = 1; w < 4; ++w)
             if (s_bv[w] < bv || (s_bv[w] == bv && s_bi[w] < bi)) { bv = s_bv[w]; bi = s_bi[w]; }
-        if (tid == bi) { mine = INFINITY; s_m[bi >> 5] |= 1u << (bi & 31); }
+        if (tid == bi) {
+            mine = INFINITY;
+            s_m[bi >> 5] |= 1u << (bi & 31);
+            if (ids_out && p < 8) ids_out[(int64_t)blockIdx.x * 8 + p] = bi;
+        }
         __syncthreads();
     }
     if (tid < 8) mask_out[(int64_t)blockIdx.x * 8 + tid] = s_m[tid];
+}
+
+// probe = distances + selection; dist_ws: nq*256 floats of scratch
+inline int launch_probe(const float* centroids, const float* queries, int64_t D, int nq, int nprobe,
+                        float* dist_ws, uint32_t* mask_out, int32_t* ids_out, hipStream_t s) {
+    hipLaunchKernelGGL(centroid_dist_kernel, dim3(256 / PD_C, (unsigned)((nq + PD_Q - 1) / PD_Q)),
+                       dim3(256), 0, s, centroids, queries, D, nq, dist_ws);
+    if (hipGetLastError() != hipSuccess) return AURA_E_LAUNCH;
+    hipLaunchKernelGGL(probe_select_kernel, dim3((unsigned)nq), dim3(256), 0, s, dist_ws, nprobe,
+                       mask_out, ids_out);
+    return hipGetLastError() == hipSuccess ? AURA_OK : AURA_E_LAUNCH;
+}
+
+// ------------------------------------------------------------------------------------------
+// Inverted-list (IVF) recall: the reference's centroid-candidate retrieval
+// (hippocampal.py:259-270) done the way the index is meant to be used -- each query touches only
+// the rows of its `nprobe` nearest centroids.  The bank rows are grouped by centroid through
+// `list_rows` (row ids sorted by centroid id, built by the host module from memory_metadata[:,2]);
+// a batch of queries is regrouped BY LIST, so every probed list is streamed from HBM once per
+// batch and scored against all the queries that probe it:
+//   ivf_prepare_kernel : per-list query lists, per-(query, probe) output offsets, 256-row groups
+//   ivf_scan_kernel    : one workgroup = (list, 256-row group, 32-query tile); 8 waves x 32 rows,
+//                        queries as the MFMA A operand, same k order and epilogue arithmetic as the
+//                        full scan (bit-identical scores); scores land at deterministic slots
+//                        cand[q][offset(q, probe) + position in list] -- no atomics
+//   topk_select_kernel : exact top-k over each query's slots
+// HBM-bound: N*D*4 bytes per batch (every list is probed by some query at nq = 256) against
+// 2*nq*nprobe*(N/256)*D useful FLOP.
+// ------------------------------------------------------------------------------------------
+constexpr int IVF_MAXQ = 256;      // queries per prepare / scan call
+constexpr int IVF_GROUP = 256;     // bank rows per workgroup
+
+struct IvfArgs {
+    const float* bank;
+    const float* inv_norm;
+    const float* meta;
+    const float* queries;     // [nq][D]
+    const float* inv_q;       // [nq]
+    const int32_t* list_rows; // row ids grouped by centroid
+    const int32_t* list_off;  // [257] start of each list inside list_rows
+    const int32_t* list_len;  // [256]
+    const int32_t* lq_cnt;    // [256] queries probing each list
+    const int32_t* lq_list;   // [256][IVF_MAXQ] packed (q << 4 | probe slot)
+    const int32_t* qbase;     // [nq][8] output offset of each (query, probe slot)
+    const int32_t* grp_off;   // [257] prefix of ceil(len/256) over lists
+    float* cand_scores;       // [nq][cap]
+    int32_t* cand_idx;
+    int cap;
+    float now;
+    int64_t D;
+    int nq;
+};
+
+__global__ __launch_bounds__(256) void ivf_prepare_kernel(const int32_t* __restrict__ probe_ids,
+                                                          int nprobe, int nq,
+                                                          const int32_t* __restrict__ list_len,
+                                                          int32_t* lq_cnt, int32_t* lq_list,
+                                                          int32_t* qbase, int32_t* qcnt,
+                                                          int32_t* grp_off, int cap,
+                                                          int32_t* overflow) {
+    __shared__ int s_cnt[256];
+    __shared__ int s_grp[257];
+    const int tid = threadIdx.x;
+    s_cnt[tid] = 0;
+    const int len = list_len[tid];
+    s_grp[tid + 1] = (len + IVF_GROUP - 1) / IVF_GROUP;
+    if (tid == 0) s_grp[0] = 0;
+    __syncthreads();
+    if (tid == 0)
+        for (int c = 1; c <= 256; ++c) s_grp[c] += s_grp[c - 1];
+    if (tid < nq) {
+        int running = 0;
+        for (int p = 0; p < nprobe; ++p) {
+            const int c = probe_ids[tid * 8 + p];
+            qbase[tid * 8 + p] = running;
+            running += list_len[c];
+            const int slot = atomicAdd(&s_cnt[c], 1);
+            lq_list[c * IVF_MAXQ + slot] = (tid << 4) | p;
+        }
+        if (running > cap) {
+            running = cap;
+            if (overflow) *overflow = 1;
+        }
+        qcnt[(int64_t)tid * CNT_STRIDE] = running;
+    }
+    __syncthreads();
+    lq_cnt[tid] = s_cnt[tid];
+    grp_off[tid] = s_grp[tid];
+    if (tid == 0) grp_off[256] = s_grp[256];
+}
+
+template <bool VEC4>
+__global__ __launch_bounds__(SCAN_THREADS) void ivf_scan_kernel(const IvfArgs a) {
+    constexpr int BQ = 32, BR = IVF_GROUP;
+    constexpr int NV = (BQ + BR) * (BK / 4);
+    constexpr int NLD = (NV + SCAN_THREADS - 1) / SCAN_THREADS;   // 5
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Qs = smem;
+    float* Bs = smem + BQ * LDS_STRIDE;
+    __shared__ int s_q[BQ];      // packed (q << 4 | p) of the tile's queries, -1 = none
+    __shared__ int s_rid[BR];    // bank row of each slot, -1 = past the end of the list
+
+    // (list, group) of this workgroup: binary search in the group prefix
+    const int b = blockIdx.x;
+    if (b >= a.grp_off[256]) return;
+    int lo = 0, hi = 256;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (a.grp_off[mid] <= b) lo = mid; else hi = mid;
+    }
+    const int c = lo;
+    const int g = b - a.grp_off[c];
+    const int nql = a.lq_cnt[c];
+    const int qt = blockIdx.y;
+    if (qt * BQ >= nql) return;
+    const int len = a.list_len[c];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    const int64_t D = a.D;
+
+    if (tid < BQ) s_q[tid] = (qt * BQ + tid < nql) ? a.lq_list[c * IVF_MAXQ + qt * BQ + tid] : -1;
+    if (tid < BR) {
+        const int pos = g * BR + tid;
+        s_rid[tid] = pos < len ? a.list_rows[a.list_off[c] + pos] : -1;
+    }
+    __syncthreads();
+
+    const float* src[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int f = tid + i * SCAN_THREADS;
+        src[i] = nullptr;
+        if (f < NV) {
+            const int r = f >> 3, col = (f & 7) * 4;
+            if (r < BQ) {
+                const int pk = s_q[r];
+                if (pk >= 0) src[i] = a.queries + (int64_t)(pk >> 4) * D + col;
+            } else {
+                const int rid = s_rid[r - BQ];
+                if (rid >= 0) src[i] = a.bank + (int64_t)rid * D + col;
+            }
+        }
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+    // one k-tile of loads in flight per workgroup; three workgroups per CU overlap each other's
+    // waits (a second register set of loads in flight measured slower: 0.134 vs 0.105 ms)
+    float4 pre[NLD];
+    auto gload = [&](int64_t k0) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int f = tid + i * SCAN_THREADS;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f < NV && src[i]) {
+                const int64_t k = k0 + (f & 7) * 4;
+                if (VEC4) {
+                    if (k < D) v = *reinterpret_cast<const float4*>(src[i] + k0);
+                } else {
+                    if (k + 0 < D) v.x = src[i][k0 + 0];
+                    if (k + 1 < D) v.y = src[i][k0 + 1];
+                    if (k + 2 < D) v.z = src[i][k0 + 2];
+                    if (k + 3 < D) v.w = src[i][k0 + 3];
+                }
+            }
+            pre[i] = v;
+        }
+    };
+    const int64_t KT = (D + BK - 1) / BK;
+    gload(0);
+    for (int64_t kt = 0; kt < KT; ++kt) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int f = tid + i * SCAN_THREADS;
+            if (f < NV) *reinterpret_cast<float4*>(smem + (f >> 3) * LDS_STRIDE + (f & 7) * 4) = pre[i];
+        }
+        __syncthreads();
+        if (kt + 1 < KT) gload((kt + 1) * BK);
+        const float* qrow = Qs + li * LDS_STRIDE + 4 * lh;
+        const float* brow = Bs + (wave * 32 + li) * LDS_STRIDE + 4 * lh;
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            const float4 av = *reinterpret_cast<const float4*>(qrow + kk * 8);
+            const float4 bv = *reinterpret_cast<const float4*>(brow + kk * 8);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // epilogue: lane = list slot (wave*32 + li) x 16 queries of the tile
+    const int slot = wave * 32 + li;
+    const int rid = s_rid[slot];
+    if (rid < 0) return;
+    const float inv_m = a.inv_norm[rid];
+    const float4 m = *reinterpret_cast<const float4*>(a.meta + (int64_t)rid * 4);
+    const float tw = 0.2f * expf(-(a.now - m.y) / 3600.0f);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int pk = s_q[(e & 3) + 8 * (e >> 2) + 4 * lh];
+        if (pk < 0) continue;
+        const int q = pk >> 4, p = pk & 15;
+        const float sim = acc[e] * a.inv_q[q] * inv_m;
+        const float comb = (0.5f * sim + tw) * m.x;
+        const int dst = a.qbase[q * 8 + p] + g * BR + slot;
+        if (dst < a.cap) {
+            a.cand_scores[(int64_t)q * a.cap + dst] = comb;
+            a.cand_idx[(int64_t)q * a.cap + dst] = rid;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -937,7 +1197,8 @@ __global__ __launch_bounds__(256) void query_prep_kernel(const float* __restrict
 // are either appended to a candidate list (unsorted) or bitonic-sorted and written out.
 // ------------------------------------------------------------------------------------------
 constexpr int SEL_THREADS = 256;
-constexpr int SEL_LDS_KEYS = 8192;  // 64 KiB of keys
+constexpr int SEL_LDS_KEYS = 8192;        // 64 KiB of keys: default chunk (2 workgroups per CU)
+constexpr int SEL_LDS_KEYS_HARD = 16384;  // 128 KiB: the most one workgroup can hold
 constexpr int SEL_MAX_K = 1024;
 
 struct SelectArgs {
@@ -1153,6 +1414,7 @@ struct Workspace {
     uint32_t* thr;       // [QBLOCK]
     int32_t* cnt;        // [QBLOCK][CNT_STRIDE]
     uint32_t* probe;     // [QBLOCK][8]
+    float* probe_dist;   // [QBLOCK][256]
     float* cand_scores;  // [qb][cap]
     int32_t* cand_idx;   // [qb][cap]
     float* cand2_scores; // [qb][cap2]  (reduce ping-pong)
@@ -1186,6 +1448,7 @@ inline Workspace carve(void* base, int64_t N, int64_t nq, int k) {
     w.thr = reinterpret_cast<uint32_t*>(take(QBLOCK * 4));
     w.cnt = reinterpret_cast<int32_t*>(take(QBLOCK * CNT_STRIDE * 4));
     w.probe = reinterpret_cast<uint32_t*>(take(QBLOCK * 32));
+    w.probe_dist = reinterpret_cast<float*>(take((int64_t)QBLOCK * 256 * 4));
     w.cand_scores = reinterpret_cast<float*>(take((int64_t)qb * w.cap * 4));
     w.cand_idx = reinterpret_cast<int32_t*>(take((int64_t)qb * w.cap * 4));
     w.cand2_scores = reinterpret_cast<float*>(take((int64_t)qb * w.cap2 * 4));
@@ -1203,11 +1466,11 @@ inline int launch_select(const SelectArgs& a, int64_t nchunks, int nq, hipStream
         // the final select keeps 8192 64-bit keys (64 KiB) + 9 KiB static in LDS
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(topk_select_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
-                                SEL_LDS_KEYS * 8) != hipSuccess)
+                                SEL_LDS_KEYS_HARD * 8) != hipSuccess)
             return AURA_E_LAUNCH;
         attr_set = true;
     }
-    if (a.chunk > SEL_LDS_KEYS || a.k > SEL_MAX_K) return AURA_E_INVAL;
+    if (a.chunk > SEL_LDS_KEYS_HARD || a.k > SEL_MAX_K) return AURA_E_INVAL;
     hipLaunchKernelGGL(topk_select_kernel, dim3((unsigned)nchunks, (unsigned)nq), dim3(SEL_THREADS),
                        (size_t)a.chunk * 8, s, a);
     return check_launch();
@@ -1397,9 +1660,8 @@ int aura_knn_search_ex(const float* bank, const float* inv_norm, const float* me
         a.cap = w.cap;
         a.dense = w.dense;
         if (centroids) {
-            hipLaunchKernelGGL(centroid_probe_kernel, dim3((unsigned)nqb), dim3(256), 0, s, centroids,
-                               qptr, D, nprobe, w.probe);
-            if ((rc = check_launch())) return rc;
+            if ((rc = launch_probe(centroids, qptr, D, nqb, nprobe, w.probe_dist, w.probe, nullptr, s)))
+                return rc;
             a.probe_mask = w.probe;
         }
 
@@ -1516,6 +1778,112 @@ int aura_knn_search(const float* bank, const float* inv_norm, const float* meta,
     return aura_knn_search_ex(bank, inv_norm, meta, loc, spatial_dims, queries, q_loc, now, N, D, nq,
                               k, idx_base, out_scores, out_idx, workspace, workspace_bytes, 0,
                               nullptr, nullptr, 0, stream);
+}
+
+// workspace of the IVF path (fixed candidate capacity per query; overflow -> caller falls back)
+constexpr int IVF_CAP = 16384;
+
+struct IvfWorkspace {
+    float* inv_q; int32_t* cnt; uint32_t* probe; float* probe_dist; int32_t* probe_ids; int32_t* qbase;
+    int32_t* lq_cnt; int32_t* lq_list; int32_t* grp_off;
+    float* cand_scores; int32_t* cand_idx;
+    int64_t bytes;
+};
+
+static IvfWorkspace carve_ivf(void* base, int /*k*/) {
+    IvfWorkspace w;
+    char* p = static_cast<char*>(base);
+    int64_t off = 0;
+    auto take = [&](int64_t bytes) {
+        char* r = p ? p + off : nullptr;
+        off += align_up(bytes, 256);
+        return r;
+    };
+    w.inv_q = reinterpret_cast<float*>(take(IVF_MAXQ * 4));
+    w.cnt = reinterpret_cast<int32_t*>(take((int64_t)IVF_MAXQ * CNT_STRIDE * 4));
+    w.probe = reinterpret_cast<uint32_t*>(take(IVF_MAXQ * 32));
+    w.probe_dist = reinterpret_cast<float*>(take((int64_t)IVF_MAXQ * 256 * 4));
+    w.probe_ids = reinterpret_cast<int32_t*>(take(IVF_MAXQ * 8 * 4));
+    w.qbase = reinterpret_cast<int32_t*>(take(IVF_MAXQ * 8 * 4));
+    w.lq_cnt = reinterpret_cast<int32_t*>(take(256 * 4));
+    w.lq_list = reinterpret_cast<int32_t*>(take((int64_t)256 * IVF_MAXQ * 4));
+    w.grp_off = reinterpret_cast<int32_t*>(take(257 * 4));
+    w.cand_scores = reinterpret_cast<float*>(take((int64_t)IVF_MAXQ * IVF_CAP * 4));
+    w.cand_idx = reinterpret_cast<int32_t*>(take((int64_t)IVF_MAXQ * IVF_CAP * 4));
+    w.bytes = off;
+    return w;
+}
+
+int64_t aura_knn_ivf_workspace_bytes(int k) {
+    if (k <= 0 || k > SEL_MAX_K) return AURA_E_INVAL;
+    return carve_ivf(nullptr, k).bytes;
+}
+
+int aura_knn_search_ivf(const float* bank, const float* inv_norm, const float* meta,
+                        const float* queries, float now, int64_t N, int64_t D, int64_t nq, int k,
+                        const float* centroids, int nprobe, const int32_t* list_rows,
+                        const int32_t* list_off, const int32_t* list_len, int32_t idx_base,
+                        float* out_scores, int32_t* out_idx, void* workspace,
+                        int64_t workspace_bytes, int32_t* overflow_out, void* stream) {
+    if (N <= 0 || D <= 0 || nq < 0 || k <= 0 || k > SEL_MAX_K) return AURA_E_INVAL;
+    if (nprobe <= 0 || nprobe > 8) return AURA_E_INVAL;
+    if (nq == 0) return AURA_OK;
+    if (!bank || !inv_norm || !meta || !queries || !centroids || !list_rows || !list_off ||
+        !list_len || !out_scores || !out_idx || !workspace)
+        return AURA_E_INVAL;
+    if (reinterpret_cast<uintptr_t>(meta) & 15) return AURA_E_ALIGN;
+    if (reinterpret_cast<uintptr_t>(workspace) & 255) return AURA_E_ALIGN;
+    const IvfWorkspace w = carve_ivf(workspace, k);
+    if (w.bytes > workspace_bytes) return AURA_E_INVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int rc;
+    const size_t lds = (size_t)(32 + IVF_GROUP) * LDS_STRIDE * sizeof(float);
+    const bool vec4 = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(bank) & 15) == 0) &&
+                      ((reinterpret_cast<uintptr_t>(queries) & 15) == 0);
+    const int64_t max_groups = (N + IVF_GROUP - 1) / IVF_GROUP + 256;
+
+    for (int64_t qb0 = 0; qb0 < nq; qb0 += IVF_MAXQ) {
+        const int nqb = (int)((nq - qb0) < IVF_MAXQ ? (nq - qb0) : IVF_MAXQ);
+        const float* qptr = queries + qb0 * D;
+        hipLaunchKernelGGL(query_prep_kernel, dim3((unsigned)((nqb + 3) / 4)), dim3(256), 0, s, qptr,
+                           w.inv_q, (int64_t)nqb, D, qb0 == 0 ? overflow_out : nullptr);
+        if ((rc = check_launch())) return rc;
+        if ((rc = launch_probe(centroids, qptr, D, nqb, nprobe, w.probe_dist, w.probe, w.probe_ids, s)))
+            return rc;
+        hipLaunchKernelGGL(ivf_prepare_kernel, dim3(1), dim3(256), 0, s, w.probe_ids, nprobe, nqb,
+                           list_len, w.lq_cnt, w.lq_list, w.qbase, w.cnt, w.grp_off, IVF_CAP,
+                           overflow_out);
+        if ((rc = check_launch())) return rc;
+
+        IvfArgs a{};
+        a.bank = bank; a.inv_norm = inv_norm; a.meta = meta; a.queries = qptr; a.inv_q = w.inv_q;
+        a.list_rows = list_rows; a.list_off = list_off; a.list_len = list_len;
+        a.lq_cnt = w.lq_cnt; a.lq_list = w.lq_list; a.qbase = w.qbase; a.grp_off = w.grp_off;
+        a.cand_scores = w.cand_scores; a.cand_idx = w.cand_idx; a.cap = IVF_CAP;
+        a.now = now; a.D = D; a.nq = nqb;
+        const dim3 grid((unsigned)max_groups, (unsigned)((nqb + 31) / 32));
+        const bool prof = g_prof.on && g_prof.used < g_prof.cap;
+        if (prof) {
+            (void)hipEventRecord(g_prof.start[g_prof.used], s);
+            g_prof.rows = N; g_prof.nq = nqb;
+        }
+        if (vec4) hipLaunchKernelGGL(ivf_scan_kernel<true>, grid, dim3(SCAN_THREADS), lds, s, a);
+        else hipLaunchKernelGGL(ivf_scan_kernel<false>, grid, dim3(SCAN_THREADS), lds, s, a);
+        if ((rc = check_launch())) return rc;
+        if (prof) (void)hipEventRecord(g_prof.stop[g_prof.used++], s);
+
+        // exact top-k of each query's slots (count = total length of its probed lists); the
+        // whole 16384-slot list fits one workgroup's LDS (128 KiB of keys), so no reduce stage
+        SelectArgs fin{};
+        fin.src_scores = w.cand_scores; fin.src_idx = w.cand_idx; fin.src_qs = IVF_CAP;
+        fin.src_inner = IVF_CAP; fin.src_outer = 0;
+        fin.src_cnt = w.cnt; fin.n_max = IVF_CAP; fin.chunk = IVF_CAP; fin.blk = 1; fin.step = 1;
+        fin.row_begin = 0; fin.row_end = N; fin.k = k; fin.sorted = 1;
+        fin.dst_scores = out_scores + qb0 * k; fin.dst_idx = out_idx + qb0 * k; fin.dst_qs = k;
+        fin.idx_base = idx_base;
+        if ((rc = launch_select(fin, 1, nqb, s))) return rc;
+    }
+    return AURA_OK;
 }
 
 int aura_topk_merge(const float* in_scores, const int32_t* in_idx, int S, int64_t nq, int k,

@@ -249,6 +249,46 @@ def knn_search(bank, inv_norm, meta, queries, k: int, now: float, count: Optiona
     return out_s, out_i
 
 
+def knn_search_ivf(bank, inv_norm, meta, queries, k: int, now: float, count: int, centroids,
+                   nprobe: int, list_rows, list_off, list_len, idx_base: int = 0
+                   ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Inverted-list recall over rows [0, count): (scores [nq, k], idx [nq, k], overflow flag [1]).
+    The flag is a device tensor (non-zero: some query's probed lists exceed the slot capacity and
+    the caller must use the masked full scan); reading it is the caller's decision."""
+    _need(bank, "bank", torch.float32); _need(inv_norm, "inv_norm", torch.float32)
+    _need(meta, "meta", torch.float32); _need(queries, "queries", torch.float32)
+    _need(centroids, "centroids", torch.float32)
+    for t, n in ((list_rows, "list_rows"), (list_off, "list_off"), (list_len, "list_len")):
+        _need(t, n, torch.int32)
+    M, D = bank.shape
+    nq = queries.shape[0]
+    if queries.dim() != 2 or queries.shape[1] != D or not (0 < count <= M) or meta.shape != (M, 4):
+        raise ValueError("knn_search_ivf: shape mismatch")
+    if centroids.shape != (256, D) or not (0 < nprobe <= 8):
+        raise ValueError("knn_search_ivf: centroids must be [256, D], nprobe in [1, 8]")
+    if list_rows.numel() != count or list_off.numel() != 257 or list_len.numel() != 256:
+        raise ValueError("knn_search_ivf: list arrays do not match count")
+    if not (0 < k <= 1024):
+        raise ValueError("knn_search_ivf: k must be in [1, 1024]")
+    dev = bank.device
+    out_s = torch.empty(nq, k, dtype=torch.float32, device=dev)
+    out_i = torch.empty(nq, k, dtype=torch.int32, device=dev)
+    ovf = torch.zeros(1, dtype=torch.int32, device=dev) if nq == 0 else _ovf_flags.get(dev)
+    if ovf is None:
+        ovf = _ovf_flags[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
+    if nq == 0:
+        return out_s, out_i, ovf
+    L = lib()
+    nbytes = L.aura_knn_ivf_workspace_bytes(k)
+    ws = _workspace(dev, nbytes)
+    base = (ws.data_ptr() + 255) // 256 * 256
+    check(L.aura_knn_search_ivf(_p(bank), _p(inv_norm), _p(meta), _p(queries), now, count, D, nq, k,
+                                _p(centroids), nprobe, _p(list_rows), _p(list_off), _p(list_len),
+                                idx_base, _p(out_s), _p(out_i), base, nbytes, _p(ovf), _stream()),
+          "aura_knn_search_ivf")
+    return out_s, out_i, ovf
+
+
 def topk_merge(scores, idx, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
     """scores, idx: [S, nq, k] per-shard lists -> merged (scores [nq, k], idx [nq, k])."""
     _need(scores, "scores", torch.float32); _need(idx, "idx", torch.int32)

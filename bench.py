@@ -140,6 +140,59 @@ def secondary_neurons(dev):
     return res
 
 
+def centroid_index_recall(dev, bank, inv, meta, q, k, now, steps=30):
+    """The reference's use_centroid_index retrieval (8 nearest of 256 centroids per query,
+    hippocampal.py:259-270) through the inverted-list kernels: same bank and queries as the
+    headline run, index = one Lloyd iteration from 256 random rows (rebuild_centroids)."""
+    from aura_snn_rag_amd import _lib, ops
+    lib = _lib.load()
+    N, D = bank.shape
+    g = torch.Generator(device="cpu").manual_seed(7)
+    cent = torch.zeros(256, D, device=dev)
+    cent[:] = bank[torch.randperm(N, generator=g)[:256].to(dev)]
+    assign = ops.kmeans_assign(bank, cent, N, 256)
+    ops.kmeans_update(bank, assign, cent, 256, update_means=True)
+    assign = ops.kmeans_assign(bank, cent, N, 256)
+    meta_i = meta.clone()
+    meta_i[:, 2] = assign.float()
+    cids = assign
+    order = torch.sort(cids, stable=True).indices.to(torch.int32).contiguous()
+    lens = torch.bincount(cids.long(), minlength=256)[:256].to(torch.int32).contiguous()
+    off = torch.cat([torch.zeros(1, dtype=torch.int32, device=dev),
+                     torch.cumsum(lens, 0).to(torch.int32)]).contiguous()
+
+    def step():
+        return ops.knn_search_ivf(bank, inv, meta_i, q, k, now, N, cent, 8, order, off, lens)
+    s_i, r_i, ovf = step()
+    # agreement with the masked full scan (same candidate sets): must be identical
+    s_m, r_m = ops.knn_search(bank, inv, meta_i, q, k, now, count=N, centroids=cent, nprobe=8)
+    same = bool(torch.equal(r_i, r_m)) and bool(torch.equal(s_i, s_m)) and int(ovf.item()) == 0
+    # recall@k of the pruned search against the exact search
+    s_e, r_e = ops.knn_search(bank, inv, meta_i, q, k, now, count=N)
+    hit = (r_i.unsqueeze(2) == r_e.unsqueeze(1)).any(dim=2).float().mean().item()
+    top1 = (r_i[:, 0] == r_e[:, 0]).float().mean().item()
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    lib.aura_profile_begin(steps * 2)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    buf = (ctypes.c_float * (steps * 2))()
+    n = lib.aura_profile_end(buf, steps * 2)
+    kms = sum(buf[i] for i in range(n)) / max(n, 1)
+    probed_rows = int(lens.sum().item())      # at nq = 256 every list is probed by some query
+    bytes_alg = probed_rows * (D * 4 + 24) + q.shape[0] * D * 4
+    return {"retrievals_per_s": q.shape[0] * steps / dt, "ms_per_step": dt / steps * 1e3,
+            "nprobe": 8, "lists": 256, "identical_to_masked_full_scan": same,
+            "recall_at_k_vs_exact": hit, "top1_agreement_vs_exact": top1,
+            "roofline": {"bound": "hbm", "kernel": "ivf_scan_kernel", "achieved": bytes_alg / (kms * 1e-3) / 1e9,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "avg_kernel_ms": kms, "algorithmic_bytes_per_launch": bytes_alg, "traffic": None}}
+
+
 def cpu_baseline(bank_rows, dim, k, nq_sample):
     """The oracle's recall at the REFERENCE's cost model (bank re-normalised per query,
     hippocampal.py:273-279) on the host cores; bit-identical to the reference (tests)."""
@@ -291,6 +344,7 @@ def main():
     }
     if rank == 0 and world == 1 and not args.no_secondary:
         out["secondary"] = secondary_neurons(dev)
+        out["secondary"]["centroid_index_recall"] = centroid_index_recall(dev, bank, inv, meta, q, k, now)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.bank_rows, D, k, args.cpu_queries)
     if rank == 0:

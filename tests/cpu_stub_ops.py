@@ -95,3 +95,16 @@ def kmeans_update(bank, assign, centroids, k, counts=None, meta=None, update_mea
             counts[c] = m.sum()
     if meta is not None:
         meta[:n, 2] = assign.float()
+
+
+def knn_search_ivf(bank, inv_norm, meta, queries, k, now, count, centroids, nprobe, list_rows, list_off,
+                   list_len, idx_base=0):
+    # host-logic stand-in: the lists must describe the same candidate sets as the mask
+    n = count
+    assert int(list_off[256]) == n and int(list_len.sum()) == int((meta[:n, 2] >= 0).sum())
+    for c in range(256):
+        rows = list_rows[int(list_off[c]):int(list_off[c]) + int(list_len[c])].long()
+        assert bool((meta[rows, 2] == c).all())
+    s, i = knn_search(bank, inv_norm, meta, queries, k, now, count=count, idx_base=idx_base,
+                      centroids=centroids, nprobe=nprobe)
+    return s, i, torch.zeros(1, dtype=torch.int32)

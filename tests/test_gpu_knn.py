@@ -332,3 +332,41 @@ def test_memory_ops_match_reference_layer_loop(dev, monkeypatch):
     empty = H.HippocampalFormation(feature_dim=32, max_memories=8, n_place_cells=4, n_time_cells=3, n_grid_cells=3, device="cuda")
     z, zs = memory_ops.retrieve_memories(empty, query.to(dev), k=5)
     assert z.abs().sum() == 0 and zs.abs().sum() == 0
+
+
+@pytest.mark.parametrize("N,D,nq,k", [(3000, 32, 12, 7), (50_000, 128, 256, 32), (20_000, 64, 300, 5)])
+def test_ivf_equals_masked_full_scan(dev, N, D, nq, k):
+    """The inverted-list recall returns bit-identical scores/rows to the masked full scan (same
+    candidate sets, same arithmetic) and matches the oracle's candidate path."""
+    from aura_snn_rag_amd import ops
+    H, hf = _mk_hf(dev, D=D, M=N + 10)
+    g = torch.Generator().manual_seed(N)
+    centers = torch.randn(300, D, generator=g) * 3
+    feats = centers[torch.randint(0, 300, (N,), generator=g)] + torch.randn(N, D, generator=g)
+    hf.use_centroid_index = False
+    hf.create_episodic_memories([f"m{i}" for i in range(N)], feats)
+    hf.use_centroid_index = True
+    hf.rebuild_centroids(perm=torch.randperm(N, generator=g))
+    q = feats[torch.randint(0, N, (nq,), generator=g)] + 0.3 * torch.randn(nq, D, generator=g)
+    qd = q.to(dev).contiguous()
+    now = float(hf.memory_metadata[0, 1].item())      # rows were stamped with the real clock
+    s_ivf, r_ivf = hf.recall_batch(qd, k=k, now=now)
+    s_msk, r_msk = ops.knn_search(hf.memory_features, hf._inv_norm, hf.memory_metadata, qd, k, now,
+                                  count=N, centroids=hf.centroids, nprobe=8)
+    empty = r_msk[:, 0] < 0                      # recall_batch falls back to the full scan for these
+    assert torch.equal(r_ivf[~empty], r_msk[~empty]) and torch.equal(s_ivf[~empty], s_msk[~empty])
+    assert int((~empty).sum()) >= nq // 2
+    # a few queries against the oracle (fixed-id candidate semantics)
+    ob = O.OracleBank(N + 10, D)
+    ob.features[:N] = feats; ob.count = N
+    ob.metadata[:N] = hf.memory_metadata[:N].cpu()
+    ob.centroids = hf.centroids.cpu(); ob.index_ready = True
+    for j in range(0, nq, max(1, nq // 6)):
+        rows, sc = ob.recall(q[j], k, now)
+        got = r_ivf[j].cpu().long(); got = got[got >= 0]
+        assert got.tolist() == rows.tolist()[:len(got)] and len(got) == min(k, len(rows))
+    # writes after the build invalidate the lists; the next recall sees the new rows
+    extra = centers[:5] + 0.01 * torch.randn(5, D, generator=g)
+    hf.create_episodic_memories([f"x{i}" for i in range(5)], extra)
+    s2, r2 = hf.recall_batch(extra[2:3].to(dev), k=1, now=now)
+    assert hf._idx_to_id[int(r2[0, 0])] == "x2"
