@@ -1786,11 +1786,12 @@ constexpr int IVF_CAP = 16384;
 struct IvfWorkspace {
     float* inv_q; int32_t* cnt; uint32_t* probe; float* probe_dist; int32_t* probe_ids; int32_t* qbase;
     int32_t* lq_cnt; int32_t* lq_list; int32_t* grp_off;
-    float* cand_scores; int32_t* cand_idx;
+    float* cand_scores; int32_t* cand_idx; float* cand2_scores; int32_t* cand2_idx;
+    int cap2;
     int64_t bytes;
 };
 
-static IvfWorkspace carve_ivf(void* base, int /*k*/) {
+static IvfWorkspace carve_ivf(void* base, int k) {
     IvfWorkspace w;
     char* p = static_cast<char*>(base);
     int64_t off = 0;
@@ -1810,6 +1811,9 @@ static IvfWorkspace carve_ivf(void* base, int /*k*/) {
     w.grp_off = reinterpret_cast<int32_t*>(take(257 * 4));
     w.cand_scores = reinterpret_cast<float*>(take((int64_t)IVF_MAXQ * IVF_CAP * 4));
     w.cand_idx = reinterpret_cast<int32_t*>(take((int64_t)IVF_MAXQ * IVF_CAP * 4));
+    w.cap2 = (int)align_up((int64_t)(IVF_CAP / 2048) * k, 64);
+    w.cand2_scores = reinterpret_cast<float*>(take((int64_t)IVF_MAXQ * w.cap2 * 4));
+    w.cand2_idx = reinterpret_cast<int32_t*>(take((int64_t)IVF_MAXQ * w.cap2 * 4));
     w.bytes = off;
     return w;
 }
@@ -1872,12 +1876,21 @@ int aura_knn_search_ivf(const float* bank, const float* inv_norm, const float* m
         if ((rc = check_launch())) return rc;
         if (prof) (void)hipEventRecord(g_prof.stop[g_prof.used++], s);
 
-        // exact top-k of each query's slots (count = total length of its probed lists); the
-        // whole 16384-slot list fits one workgroup's LDS (128 KiB of keys), so no reduce stage
+        // exact top-k of each query's slots (count = total length of its probed lists), in two
+        // levels: 2048-slot chunks keep their k best (many small workgroups, 16 KiB of LDS each),
+        // then one sorted select over the chunk winners
+        constexpr int IVF_SEL_CHUNK = 2048;
+        const int64_t nch = IVF_CAP / IVF_SEL_CHUNK;
+        SelectArgs r{};
+        r.src_scores = w.cand_scores; r.src_idx = w.cand_idx; r.src_qs = IVF_CAP; r.src_inner = IVF_CAP;
+        r.src_outer = 0; r.src_cnt = w.cnt; r.n_max = IVF_CAP; r.chunk = IVF_SEL_CHUNK; r.blk = 1; r.step = 1;
+        r.row_begin = 0; r.row_end = N; r.k = k; r.sorted = 0;
+        r.dst_scores = w.cand2_scores; r.dst_idx = w.cand2_idx; r.dst_qs = w.cap2; r.dst_off = 0;
+        if ((rc = launch_select(r, nch, nqb, s))) return rc;
         SelectArgs fin{};
-        fin.src_scores = w.cand_scores; fin.src_idx = w.cand_idx; fin.src_qs = IVF_CAP;
-        fin.src_inner = IVF_CAP; fin.src_outer = 0;
-        fin.src_cnt = w.cnt; fin.n_max = IVF_CAP; fin.chunk = IVF_CAP; fin.blk = 1; fin.step = 1;
+        fin.src_scores = w.cand2_scores; fin.src_idx = w.cand2_idx; fin.src_qs = w.cap2;
+        fin.src_inner = w.cap2; fin.src_outer = 0;
+        fin.src_cnt = nullptr; fin.n_max = nch * k; fin.chunk = (int)(nch * k); fin.blk = 1; fin.step = 1;
         fin.row_begin = 0; fin.row_end = N; fin.k = k; fin.sorted = 1;
         fin.dst_scores = out_scores + qb0 * k; fin.dst_idx = out_idx + qb0 * k; fin.dst_qs = k;
         fin.idx_base = idx_base;
