@@ -869,7 +869,7 @@ inline int launch_probe(const float* centroids, const float* queries, int64_t D,
 // 2*nq*nprobe*(N/256)*D useful FLOP.
 // ------------------------------------------------------------------------------------------
 constexpr int IVF_MAXQ = 256;      // queries per prepare / scan call
-constexpr int IVF_GROUP = 256;     // bank rows per workgroup
+constexpr int IVF_GROUP = 128;     // bank rows per workgroup (4 waves x 32 rows)
 
 struct IvfArgs {
     const float* bank;
@@ -930,11 +930,13 @@ __global__ __launch_bounds__(256) void ivf_prepare_kernel(const int32_t* __restr
     if (tid == 0) grp_off[256] = s_grp[256];
 }
 
+constexpr int IVF_THREADS = IVF_GROUP * 2;   // one wave per 32 rows
+
 template <bool VEC4>
-__global__ __launch_bounds__(SCAN_THREADS) void ivf_scan_kernel(const IvfArgs a) {
+__global__ __launch_bounds__(IVF_THREADS) void ivf_scan_kernel(const IvfArgs a) {
     constexpr int BQ = 32, BR = IVF_GROUP;
     constexpr int NV = (BQ + BR) * (BK / 4);
-    constexpr int NLD = (NV + SCAN_THREADS - 1) / SCAN_THREADS;   // 5
+    constexpr int NLD = (NV + IVF_THREADS - 1) / IVF_THREADS;   // 5
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Qs = smem;
     float* Bs = smem + BQ * LDS_STRIDE;
@@ -968,7 +970,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void ivf_scan_kernel(const IvfArgs a)
     const float* src[NLD];
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-        const int f = tid + i * SCAN_THREADS;
+        const int f = tid + i * IVF_THREADS;
         src[i] = nullptr;
         if (f < NV) {
             const int r = f >> 3, col = (f & 7) * 4;
@@ -990,7 +992,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void ivf_scan_kernel(const IvfArgs a)
     auto gload = [&](int64_t k0) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            const int f = tid + i * SCAN_THREADS;
+            const int f = tid + i * IVF_THREADS;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (f < NV && src[i]) {
                 const int64_t k = k0 + (f & 7) * 4;
@@ -1011,7 +1013,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void ivf_scan_kernel(const IvfArgs a)
     for (int64_t kt = 0; kt < KT; ++kt) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            const int f = tid + i * SCAN_THREADS;
+            const int f = tid + i * IVF_THREADS;
             if (f < NV) *reinterpret_cast<float4*>(smem + (f >> 3) * LDS_STRIDE + (f & 7) * 4) = pre[i];
         }
         __syncthreads();
@@ -1871,8 +1873,8 @@ int aura_knn_search_ivf(const float* bank, const float* inv_norm, const float* m
             (void)hipEventRecord(g_prof.start[g_prof.used], s);
             g_prof.rows = N; g_prof.nq = nqb;
         }
-        if (vec4) hipLaunchKernelGGL(ivf_scan_kernel<true>, grid, dim3(SCAN_THREADS), lds, s, a);
-        else hipLaunchKernelGGL(ivf_scan_kernel<false>, grid, dim3(SCAN_THREADS), lds, s, a);
+        if (vec4) hipLaunchKernelGGL(ivf_scan_kernel<true>, grid, dim3(IVF_THREADS), lds, s, a);
+        else hipLaunchKernelGGL(ivf_scan_kernel<false>, grid, dim3(IVF_THREADS), lds, s, a);
         if ((rc = check_launch())) return rc;
         if (prof) (void)hipEventRecord(g_prof.stop[g_prof.used++], s);
 
