@@ -531,26 +531,37 @@ __global__ __launch_bounds__(SCAN_THREADS) void knn_scan_filter_v2(const ScanArg
     const int lane = tid & 63, li = lane & 31, lh = lane >> 5;
     const int64_t D = a.D;
     const int64_t KT = (D + BK - 1) / BK;
-    const int64_t lo = a.n_items * (int64_t)blockIdx.x / gridDim.x;
-    const int64_t hi = a.n_items * ((int64_t)blockIdx.x + 1) / gridDim.x;
+    // work space = (256-query block) x (non-sample 32-row tile); a workgroup owns a contiguous
+    // span of it, cut into chunks of up to 4 tiles that never straddle two query blocks
+    const int64_t nqblk = (a.nq + BQ - 1) / BQ;
+    const int64_t total = a.n_items * nqblk;
+    const int64_t lo = total * (int64_t)blockIdx.x / gridDim.x;
+    const int64_t hi = total * ((int64_t)blockIdx.x + 1) / gridDim.x;
     if (lo >= hi) return;
 
-    // staging slots of this thread: 4 query rows (fixed) + 2 bank rows (per chunk)
+    // staging slots of this thread: 4 query rows + 2 bank rows (both per chunk)
     const int srow = tid >> 3, scol = (tid & 7) * 4;
-    const float* qsrc[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int q = srow + 64 * i;
-        qsrc[i] = q < a.nq ? a.queries + (int64_t)q * D + scol : nullptr;
-    }
     const int lds_slot = srow * LDS_STRIDE + scol;
 
-    for (int64_t c = lo; c < hi; c += RT) {
+    int64_t c = lo;
+    while (c < hi) {
+        const int64_t qblk = c / a.n_items, j0 = c - qblk * a.n_items;
+        int64_t nt = hi - c;
+        if (nt > RT) nt = RT;
+        if (nt > a.n_items - j0) nt = a.n_items - j0;
+        const int qoff = (int)qblk * BQ;                 // first query of this chunk's block
+        c += nt;
+        const float* qsrc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = qoff + srow + 64 * i;
+            qsrc[i] = q < a.nq ? a.queries + (int64_t)q * D + scol : nullptr;
+        }
         int64_t row0[RT];
 #pragma unroll
         for (int r = 0; r < RT; ++r)
-            row0[r] = (c + r < hi)
-                          ? a.row_begin + filter_tile_of(c + r, a.tile_step, a.n_sample_tiles) * 32
+            row0[r] = (r < nt)
+                          ? a.row_begin + filter_tile_of(j0 + r, a.tile_step, a.n_sample_tiles) * 32
                           : a.row_end;
         const float* bsrc[2];
 #pragma unroll
@@ -645,7 +656,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void knn_scan_filter_v2(const ScanArg
         uint32_t* s_mask = reinterpret_cast<uint32_t*>(smem);
         if (!FAST && a.probe_mask) {
             for (int t = tid; t < BQ * 8; t += SCAN_THREADS) {
-                const int q = t >> 3;
+                const int q = qoff + (t >> 3);
                 s_mask[t] = q < a.nq ? a.probe_mask[(int64_t)q * 8 + (t & 7)] : 0u;
             }
             __syncthreads();
@@ -654,7 +665,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void knn_scan_filter_v2(const ScanArg
         float iq[16], thrf[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const int q = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            const int q = qoff + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
             iq[e] = q < a.nq ? a.inv_q[q] : 0.0f;
             thrf[e] = q < a.nq ? ord_unkey(a.thr[q]) : INFINITY;   // same order as the key compare
         }
@@ -691,7 +702,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void knn_scan_filter_v2(const ScanArg
                 const bool cid_ok = cid >= 0 && cid < 256;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const int q = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    const int q = qoff + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
                     const float sim = acc[r][e] * iq[e] * inv_m;
                     float comb = 0.5f * sim;
                     if (a.q_loc && q < a.nq) {
@@ -705,7 +716,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void knn_scan_filter_v2(const ScanArg
                     comb = (comb + tw) * strength;
                     bool cand = vrow && q < a.nq;
                     if (a.probe_mask)
-                        cand = cand && cid_ok && ((s_mask[q * 8 + (cid >> 5)] >> (cid & 31)) & 1u);
+                        cand = cand && cid_ok && ((s_mask[(q - qoff) * 8 + (cid >> 5)] >> (cid & 31)) & 1u);
                     acc[r][e] = comb;
                     if (cand && comb >= thrf[e]) pass |= 1ull << (r * 16 + e);
                 }
@@ -718,12 +729,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void knn_scan_filter_v2(const ScanArg
                 int n = 0;
 #pragma unroll
                 for (int r = 0; r < RT; ++r) n += (int)((pass >> (r * 16 + e)) & 1ull);
-                const int q = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                const int q = qoff + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
                 pos[e] = n > 0 ? atomicAdd(a.cnt + (int64_t)q * CNT_STRIDE, n) : 0;
             }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int q = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                const int q = qoff + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
                 int p = pos[e];
 #pragma unroll
                 for (int r = 0; r < RT; ++r) {
@@ -1406,24 +1417,25 @@ __global__ void fill_u32_kernel(uint32_t* p, uint32_t v, int64_t n) {
 // ------------------------------------------------------------------------------------------
 // Host-side search driver
 // ------------------------------------------------------------------------------------------
-constexpr int QBLOCK = 256;             // queries per pass over the bank
+constexpr int QPASS_MAX = 2048;         // most queries handled by one pass of the pipeline
 constexpr int64_t DENSE_COLS = 131072;  // dense score columns kept per query (128 MiB / 256 q)
 constexpr int SEL_CHUNK = 4096;         // dense columns per select workgroup
 constexpr int CAND_CAP_MIN = 8192;      // filter-path candidate slots per query
 
 struct Workspace {
-    float* inv_q;        // [QBLOCK]
-    uint32_t* thr;       // [QBLOCK]
-    int32_t* cnt;        // [QBLOCK][CNT_STRIDE]
-    uint32_t* probe;     // [QBLOCK][8]
-    float* probe_dist;   // [QBLOCK][256]
-    float* cand_scores;  // [qb][cap]
+    float* inv_q;        // [qp]            (qp = queries per pass)
+    uint32_t* thr;       // [qp]
+    int32_t* cnt;        // [qp][CNT_STRIDE]
+    uint32_t* probe;     // [qp][8]
+    float* probe_dist;   // [qp][256]
+    float* cand_scores;  // [qp][cap]
     int32_t* cand_idx;   // [qb][cap]
     float* cand2_scores; // [qb][cap2]  (reduce ping-pong)
     int32_t* cand2_idx;
     float* dense;        // [qb][dense cols]
     float* gmax;         // [qb][THR_MAX_GROUPS]
     int cap, cap2;
+    int qp;              // queries per pass
     int64_t bytes;
 };
 
@@ -1438,7 +1450,12 @@ inline Workspace carve(void* base, int64_t N, int64_t nq, int k) {
     Workspace w;
     char* p = static_cast<char*>(base);
     int64_t off = 0;
-    const int qb = (int)(nq < QBLOCK ? (nq > 0 ? nq : 1) : QBLOCK);
+    // queries per pass: as many as fit a 1 GiB dense-score buffer, at most QPASS_MAX
+    const int64_t cols = N < DENSE_COLS ? align_up(N > 0 ? N : 1, 1024) : DENSE_COLS;
+    int64_t qp = nq < QPASS_MAX ? (nq > 0 ? nq : 1) : QPASS_MAX;
+    while (qp > 256 && qp * cols * 4 > (int64_t(1) << 30)) qp = (qp / 2 + 255) / 256 * 256;
+    const int qb = (int)qp;
+    w.qp = qb;
     auto take = [&](int64_t bytes) {
         char* r = p ? p + off : nullptr;
         off += align_up(bytes, 256);
@@ -1446,16 +1463,15 @@ inline Workspace carve(void* base, int64_t N, int64_t nq, int k) {
     };
     w.cap = cand_cap(N, k);
     w.cap2 = (int)align_up(((int64_t)w.cap + SEL_LDS_KEYS - 1) / SEL_LDS_KEYS * k, 64);
-    w.inv_q = reinterpret_cast<float*>(take(QBLOCK * 4));
-    w.thr = reinterpret_cast<uint32_t*>(take(QBLOCK * 4));
-    w.cnt = reinterpret_cast<int32_t*>(take(QBLOCK * CNT_STRIDE * 4));
-    w.probe = reinterpret_cast<uint32_t*>(take(QBLOCK * 32));
-    w.probe_dist = reinterpret_cast<float*>(take((int64_t)QBLOCK * 256 * 4));
+    w.inv_q = reinterpret_cast<float*>(take((int64_t)qb * 4));
+    w.thr = reinterpret_cast<uint32_t*>(take((int64_t)qb * 4));
+    w.cnt = reinterpret_cast<int32_t*>(take((int64_t)qb * CNT_STRIDE * 4));
+    w.probe = reinterpret_cast<uint32_t*>(take((int64_t)qb * 32));
+    w.probe_dist = reinterpret_cast<float*>(take((int64_t)qb * 256 * 4));
     w.cand_scores = reinterpret_cast<float*>(take((int64_t)qb * w.cap * 4));
     w.cand_idx = reinterpret_cast<int32_t*>(take((int64_t)qb * w.cap * 4));
     w.cand2_scores = reinterpret_cast<float*>(take((int64_t)qb * w.cap2 * 4));
     w.cand2_idx = reinterpret_cast<int32_t*>(take((int64_t)qb * w.cap2 * 4));
-    const int64_t cols = N < DENSE_COLS ? align_up(N > 0 ? N : 1, 1024) : DENSE_COLS;
     w.dense = reinterpret_cast<float*>(take((int64_t)qb * cols * 4));
     w.gmax = reinterpret_cast<float*>(take((int64_t)qb * THR_MAX_GROUPS * 4));
     w.bytes = off;
@@ -1541,7 +1557,7 @@ inline int launch_filter_v2(const ScanArgs& a, hipStream_t s) {
     }
     if (a.n_items <= 0) return AURA_OK;
     int64_t grid = device_cu_count();
-    const int64_t chunks = (a.n_items + 3) / 4;
+    const int64_t chunks = ((a.n_items + 3) / 4) * ((a.nq + 255) / 256);
     if (grid > chunks) grid = chunks;
     const bool vec4 = (a.D % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.bank) & 15) == 0) &&
                       ((reinterpret_cast<uintptr_t>(a.queries) & 15) == 0);
@@ -1642,8 +1658,8 @@ int aura_knn_search_ex(const float* bank, const float* inv_norm, const float* me
     hipStream_t s = static_cast<hipStream_t>(stream);
     int rc;
 
-    for (int64_t qb0 = 0; qb0 < nq; qb0 += QBLOCK) {
-        const int nqb = (int)((nq - qb0) < QBLOCK ? (nq - qb0) : QBLOCK);
+    for (int64_t qb0 = 0; qb0 < nq; qb0 += w.qp) {
+        const int nqb = (int)((nq - qb0) < w.qp ? (nq - qb0) : w.qp);
         const float* qptr = queries + qb0 * D;
         const int br = tile_rows_for(nqb);
         const int64_t ntiles = (N + br - 1) / br;
@@ -1675,8 +1691,12 @@ int aura_knn_search_ex(const float* bank, const float* inv_norm, const float* me
         sel.cnt_out = w.cnt; sel.row_end = N;
 
         // filter path: expected candidates per query ~ k*N/sample_rows; aim for <= ~512
+        //   floor: 8192 rows for large banks, N/8 for small ones (row shards of a multi-GPU bank),
+        //   never fewer than 1.5 k groups of 32 rows (the bound is the k-th largest group maximum)
         int64_t sample_rows = (int64_t)k * N / 512;
-        if (sample_rows < 8192) sample_rows = 8192;
+        int64_t floor_rows = N / 8 < 8192 ? N / 8 : 8192;
+        if (floor_rows < (int64_t)k * 48) floor_rows = (int64_t)k * 48;
+        if (sample_rows < floor_rows) sample_rows = floor_rows;
         const int64_t n_sample_tiles = (sample_rows + br - 1) / br;
         const bool dense_all = (flags & AURA_KNN_FORCE_DENSE) || n_sample_tiles * 4 > ntiles ||
                                n_sample_tiles * br > DENSE_COLS ||
@@ -1684,7 +1704,7 @@ int aura_knn_search_ex(const float* bank, const float* inv_norm, const float* me
         int64_t cur_n;  // candidate slots in use (capacity view) after this stage
         const int32_t* cur_cnt;
         if (dense_all) {
-            if (hipMemsetAsync(w.cnt, 0, QBLOCK * CNT_STRIDE * 4, s) != hipSuccess) return AURA_E_LAUNCH;
+            if (hipMemsetAsync(w.cnt, 0, (size_t)w.qp * CNT_STRIDE * 4, s) != hipSuccess) return AURA_E_LAUNCH;
             const int64_t tiles_per_super = DENSE_COLS / br;
             int64_t appended = 0;
             for (int64_t t0 = 0; t0 < ntiles; t0 += tiles_per_super) {
@@ -1728,7 +1748,7 @@ int aura_knn_search_ex(const float* bank, const float* inv_norm, const float* me
             if (prof) {
                 (void)hipEventRecord(g_prof.start[g_prof.used], s);
                 g_prof.rows = N - n_sample_tiles * br;
-                g_prof.nq = nqb;
+                g_prof.nq = nqb;   // all query blocks of the pass are scored by this one launch
             }
             static const bool force_v1 = getenv("AURA_SCAN_V1") != nullptr;
             if (nqb > 128 && !force_v1) {

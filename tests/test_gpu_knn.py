@@ -47,6 +47,8 @@ def _search(dev, bank, meta, q, k, **kw):
     (600, 32, 8, 10), (5000, 64, 1, 5), (5000, 64, 7, 1), (5000, 64, 33, 32), (5000, 64, 100, 32),
     (5000, 64, 256, 32), (3000, 48, 300, 5), (20000, 128, 64, 32), (257, 4, 5, 5), (129, 768, 3, 129),
     (70000, 64, 16, 32), (70000, 64, 256, 8),
+    (9000, 64, 700, 10),          # filter path over 3 query blocks in one pass
+    (12500, 768, 2048, 32),       # one rank's share of `bench.py --gpus 8`: 8 query blocks x 12.5k rows
 ])
 def test_exact_search_matches_oracle(dev, N, D, nq, k):
     bank, g = _bank(N, D, seed=N + D)
