@@ -104,3 +104,39 @@ def test_zone_and_addition_linear_bit_exact():
     x = torch.randn(5, 20)
     with torch.no_grad():
         assert torch.equal(al(x), O.addition_linear(x, al.weight_patterns, al.bias))
+
+
+def test_product_modules_construct_like_the_reference():
+    """Same constructor arguments -> same state_dict keys, shapes and (seeded) initial values: an
+    upstream checkpoint loads into the product modules unchanged."""
+    from aura_snn_rag_amd.base.neuron import AdExNeuron, IzhikevichNeuron, VectorizedLIFNeuron
+    from aura_snn_rag_amd.core.hippocampal import HippocampalFormation
+    from aura_snn_rag_amd.core.language_zone.gif_neuron import BalancedGIFNeuron, GIFNeuron
+    from aura_snn_rag_amd.core.language_zone.snn_ffn import HybridFFN, SNNFFN
+    from aura_snn_rag_amd.core.language_zone.synapsis import Synapsis
+    from aura_snn_rag_amd.maths.addition_linear import AdditionLinear
+    R = {"hip": L.load("core.hippocampal"), "neu": L.load("base.neuron"),
+         "gif": L.load("src.core.language_zone.gif_neuron"), "ffn": L.load("src.core.language_zone.snn_ffn"),
+         "syn": L.load("src.core.language_zone.synapsis"), "al": L.load("src.maths.addition_linear")}
+    cases = [
+        (lambda: R["hip"].HippocampalFormation(2, 30, 10, 20, 50, 16, "cpu"), lambda: HippocampalFormation(2, 30, 10, 20, 50, 16, "cpu")),
+        (lambda: R["neu"].IzhikevichNeuron(0.1, 0.26, -60, 0, 0.5), lambda: IzhikevichNeuron(0.1, 0.26, -60, 0, 0.5)),
+        (lambda: R["neu"].AdExNeuron(a=2.0, b=60.0), lambda: AdExNeuron(a=2.0, b=60.0)),
+        (lambda: R["neu"].VectorizedLIFNeuron(12, 0.9, 0.4), lambda: VectorizedLIFNeuron(12, 0.9, 0.4)),
+        (lambda: R["gif"].GIFNeuron(6, 10, L=8), lambda: GIFNeuron(6, 10, L=8)),
+        (lambda: R["gif"].BalancedGIFNeuron(6, 10, L=8), lambda: BalancedGIFNeuron(6, 10, L=8)),
+        (lambda: R["syn"].Synapsis(9, 4), lambda: Synapsis(9, 4)),
+        (lambda: R["ffn"].SNNFFN(16, 32), lambda: SNNFFN(16, 32)),
+        (lambda: R["ffn"].HybridFFN(16, 32), lambda: HybridFFN(16, 32)),
+        (lambda: R["al"].AdditionLinear(7, 5, bias=True), lambda: AdditionLinear(7, 5, bias=True)),
+    ]
+    for make_ref, make_ours in cases:
+        torch.manual_seed(11); ref = make_ref().state_dict()
+        torch.manual_seed(11); ours = make_ours().state_dict()
+        assert list(ref) == list(ours), (list(ref), list(ours))
+        for k in ref:
+            assert ref[k].shape == ours[k].shape and ref[k].dtype == ours[k].dtype, k
+            assert torch.equal(ref[k], ours[k]), k
+    g = GIFNeuron(6, 10, L=8)
+    r = R["gif"].GIFNeuron(6, 10, L=8)
+    assert (g.decay, g.threshold, g.alpha, g.L) == (r.decay, r.threshold, r.alpha, r.L)
