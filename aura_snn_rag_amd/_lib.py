@@ -40,8 +40,8 @@ SIGNATURES = {
     "aura_knn_search": (I, [P, P, P, P, I, P, P, F, I64, I64, I64, I, I32, P, P, P, I64, P]),
     "aura_knn_search_ex": (I, [P, P, P, P, I, P, P, F, I64, I64, I64, I, I32, P, P, P, I64, I, P,
                                P, I, P]),
-    "aura_knn_ivf_workspace_bytes": (I64, [I]),
-    "aura_knn_search_ivf": (I, [P, P, P, P, F, I64, I64, I64, I, P, I, P, P, P, I32, P, P, P, I64, P, P]),
+    "aura_knn_ivf_workspace_bytes": (I64, [I64, I, I]),
+    "aura_knn_search_ivf": (I, [P, P, P, P, F, I64, I64, I64, I, P, I, P, P, P, I, I32, P, P, P, I64, P, P]),
     "aura_topk_merge": (I, [P, P, I, I64, I, P, P, P]),
     "aura_bank_gather": (I, [P, P, P, I64, I64, P]),
     "aura_kmeans_assign": (I, [P, P, P, P, I64, I64, I, P]),

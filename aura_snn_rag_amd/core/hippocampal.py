@@ -136,7 +136,10 @@ class HippocampalFormation(nn.Module):
                                   minlength=256)[:256].to(torch.int32)
             n_neg = (n - valid.sum()).to(torch.int32).reshape(1)
             off = torch.cat([n_neg, n_neg + torch.cumsum(lens, 0).to(torch.int32)]).contiguous()
-            self._lists = (order.contiguous(), off, lens.contiguous())
+            # slots per query: no query can collect more rows than the 8 longest lists hold
+            # (one host read per list rebuild, not per recall)
+            longest = int(torch.topk(lens, min(8, lens.numel())).values.sum().item())
+            self._lists = (order.contiguous(), off, lens.contiguous(), longest)
             self._lists_count = n
         return self._lists
 
@@ -338,12 +341,13 @@ class HippocampalFormation(nn.Module):
         scores = rows = None
         if q_loc is None and self.centroids.shape[0] == 256:
             # inverted-list form: every probed list is streamed once per batch
-            list_rows, list_off, list_len = self._ensure_lists()
-            scores, rows, ovf = ops.knn_search_ivf(self.memory_features, self._inv_norm,
-                                                   self.memory_metadata, q, kk, now, self.memory_count,
-                                                   self.centroids, nprobe, list_rows, list_off, list_len)
-            if check_overflow and int(ovf.item()) != 0:
-                scores = rows = None          # a query's lists exceed the slot capacity
+            list_rows, list_off, list_len, longest = self._ensure_lists()
+            cap = ops.ivf_capacity(longest, kk)
+            if cap is not None:               # else: lists too long for the two-level select
+                scores, rows, _ = ops.knn_search_ivf(self.memory_features, self._inv_norm,
+                                                     self.memory_metadata, q, kk, now, self.memory_count,
+                                                     self.centroids, nprobe, list_rows, list_off,
+                                                     list_len, cap)
         if scores is None:
             scores, rows = ops.knn_search(self.memory_features, self._inv_norm, self.memory_metadata,
                                           q, kk, now, centroids=self.centroids, nprobe=nprobe, **kw)

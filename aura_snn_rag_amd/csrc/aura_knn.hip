@@ -879,8 +879,9 @@ inline int launch_probe(const float* centroids, const float* queries, int64_t D,
 // HBM-bound: N*D*4 bytes per batch (every list is probed by some query at nq = 256) against
 // 2*nq*nprobe*(N/256)*D useful FLOP.
 // ------------------------------------------------------------------------------------------
-constexpr int IVF_MAXQ = 256;      // queries per prepare / scan call
-constexpr int IVF_GROUP = 128;     // bank rows per workgroup (4 waves x 32 rows)
+constexpr int IVF_MAXQ = 2048;     // queries per pass (per prepare / scan launch)
+constexpr int IVF_GROUP = 128;     // bank rows per work item (4 waves x 32 rows)
+constexpr int IVF_THREADS = IVF_GROUP * 2;
 
 struct IvfArgs {
     const float* bank;
@@ -894,7 +895,8 @@ struct IvfArgs {
     const int32_t* lq_cnt;    // [256] queries probing each list
     const int32_t* lq_list;   // [256][IVF_MAXQ] packed (q << 4 | probe slot)
     const int32_t* qbase;     // [nq][8] output offset of each (query, probe slot)
-    const int32_t* grp_off;   // [257] prefix of ceil(len/256) over lists
+    const int32_t* item_off;  // [257] prefix over lists of ceil(len/128) * ceil(queries/32)
+    int32_t* work_counter;    // [1] next unclaimed work item (zeroed by ivf_prepare_kernel)
     float* cand_scores;       // [nq][cap]
     int32_t* cand_idx;
     int cap;
@@ -908,159 +910,177 @@ __global__ __launch_bounds__(256) void ivf_prepare_kernel(const int32_t* __restr
                                                           const int32_t* __restrict__ list_len,
                                                           int32_t* lq_cnt, int32_t* lq_list,
                                                           int32_t* qbase, int32_t* qcnt,
-                                                          int32_t* grp_off, int cap,
-                                                          int32_t* overflow) {
+                                                          int32_t* item_off, int32_t* work_counter,
+                                                          int cap, int qtile, int32_t* overflow) {
     __shared__ int s_cnt[256];
-    __shared__ int s_grp[257];
+    __shared__ int s_item[257];
     const int tid = threadIdx.x;
     s_cnt[tid] = 0;
-    const int len = list_len[tid];
-    s_grp[tid + 1] = (len + IVF_GROUP - 1) / IVF_GROUP;
-    if (tid == 0) s_grp[0] = 0;
     __syncthreads();
-    if (tid == 0)
-        for (int c = 1; c <= 256; ++c) s_grp[c] += s_grp[c - 1];
-    if (tid < nq) {
+    for (int q = tid; q < nq; q += 256) {
         int running = 0;
         for (int p = 0; p < nprobe; ++p) {
-            const int c = probe_ids[tid * 8 + p];
-            qbase[tid * 8 + p] = running;
+            const int c = probe_ids[q * 8 + p];
+            qbase[q * 8 + p] = running;
             running += list_len[c];
             const int slot = atomicAdd(&s_cnt[c], 1);
-            lq_list[c * IVF_MAXQ + slot] = (tid << 4) | p;
+            lq_list[c * IVF_MAXQ + slot] = (q << 4) | p;
         }
         if (running > cap) {
             running = cap;
             if (overflow) *overflow = 1;
         }
-        qcnt[(int64_t)tid * CNT_STRIDE] = running;
+        qcnt[(int64_t)q * CNT_STRIDE] = running;
     }
     __syncthreads();
     lq_cnt[tid] = s_cnt[tid];
-    grp_off[tid] = s_grp[tid];
-    if (tid == 0) grp_off[256] = s_grp[256];
+    s_item[tid + 1] = ((list_len[tid] + IVF_GROUP - 1) / IVF_GROUP) * ((s_cnt[tid] + qtile - 1) / qtile);
+    if (tid == 0) { s_item[0] = 0; *work_counter = 0; }
+    __syncthreads();
+    if (tid == 0)
+        for (int c = 1; c <= 256; ++c) s_item[c] += s_item[c - 1];
+    __syncthreads();
+    item_off[tid] = s_item[tid];
+    if (tid == 0) item_off[256] = s_item[256];
 }
 
-constexpr int IVF_THREADS = IVF_GROUP * 2;   // one wave per 32 rows
-
-template <bool VEC4>
+// Persistent: workgroups claim (list, 128-row group, QT*32-query tile) items from a global counter
+// until none is left; items of one row group with different query tiles are adjacent, so the
+// group's rows are re-read from L2, not HBM.
+// QT = 1 for small batches (a list is probed by ~nq/32 queries), QT = 2 when lists see >= 64
+// queries: twice the MFMA work per staged row tile and half the items.
+template <bool VEC4, int QT>
 __global__ __launch_bounds__(IVF_THREADS) void ivf_scan_kernel(const IvfArgs a) {
-    constexpr int BQ = 32, BR = IVF_GROUP;
+    constexpr int BQ = 32 * QT, BR = IVF_GROUP;
     constexpr int NV = (BQ + BR) * (BK / 4);
-    constexpr int NLD = (NV + IVF_THREADS - 1) / IVF_THREADS;   // 5
+    constexpr int NLD = (NV + IVF_THREADS - 1) / IVF_THREADS;   // 5 (QT = 1) or 6 (QT = 2)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Qs = smem;
     float* Bs = smem + BQ * LDS_STRIDE;
     __shared__ int s_q[BQ];      // packed (q << 4 | p) of the tile's queries, -1 = none
     __shared__ int s_rid[BR];    // bank row of each slot, -1 = past the end of the list
+    __shared__ int s_item;
 
-    // (list, group) of this workgroup: binary search in the group prefix
-    const int b = blockIdx.x;
-    if (b >= a.grp_off[256]) return;
-    int lo = 0, hi = 256;
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (a.grp_off[mid] <= b) lo = mid; else hi = mid;
-    }
-    const int c = lo;
-    const int g = b - a.grp_off[c];
-    const int nql = a.lq_cnt[c];
-    const int qt = blockIdx.y;
-    if (qt * BQ >= nql) return;
-    const int len = a.list_len[c];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
     const int64_t D = a.D;
+    const int64_t KT = (D + BK - 1) / BK;
+    const int total = a.item_off[256];
 
-    if (tid < BQ) s_q[tid] = (qt * BQ + tid < nql) ? a.lq_list[c * IVF_MAXQ + qt * BQ + tid] : -1;
-    if (tid < BR) {
-        const int pos = g * BR + tid;
-        s_rid[tid] = pos < len ? a.list_rows[a.list_off[c] + pos] : -1;
-    }
-    __syncthreads();
-
-    const float* src[NLD];
-#pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-        const int f = tid + i * IVF_THREADS;
-        src[i] = nullptr;
-        if (f < NV) {
-            const int r = f >> 3, col = (f & 7) * 4;
-            if (r < BQ) {
-                const int pk = s_q[r];
-                if (pk >= 0) src[i] = a.queries + (int64_t)(pk >> 4) * D + col;
-            } else {
-                const int rid = s_rid[r - BQ];
-                if (rid >= 0) src[i] = a.bank + (int64_t)rid * D + col;
-            }
+    for (;;) {
+        if (tid == 0) s_item = atomicAdd(a.work_counter, 1);
+        __syncthreads();
+        const int item = s_item;
+        if (item >= total) break;
+        int lo = 0, hi = 256;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (a.item_off[mid] <= item) lo = mid; else hi = mid;
         }
-    }
-    f32x16 acc;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
-    // one k-tile of loads in flight per workgroup; three workgroups per CU overlap each other's
-    // waits (a second register set of loads in flight measured slower: 0.134 vs 0.105 ms)
-    float4 pre[NLD];
-    auto gload = [&](int64_t k0) {
+        const int c = lo;
+        const int len = a.list_len[c], nql = a.lq_cnt[c];
+        const int nqt = (nql + BQ - 1) / BQ;
+        const int local = item - a.item_off[c];
+        const int g = local / nqt, qt = local - g * nqt;
+
+        if (tid < BQ) s_q[tid] = (qt * BQ + tid < nql) ? a.lq_list[c * IVF_MAXQ + qt * BQ + tid] : -1;
+        if (tid < BR) {
+            const int pos = g * BR + tid;
+            s_rid[tid] = pos < len ? a.list_rows[a.list_off[c] + pos] : -1;
+        }
+        __syncthreads();
+
+        const float* src[NLD];
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int f = tid + i * IVF_THREADS;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (f < NV && src[i]) {
-                const int64_t k = k0 + (f & 7) * 4;
-                if (VEC4) {
-                    if (k < D) v = *reinterpret_cast<const float4*>(src[i] + k0);
+            src[i] = nullptr;
+            if (f < NV) {
+                const int r = f >> 3, col = (f & 7) * 4;
+                if (r < BQ) {
+                    const int pk = s_q[r];
+                    if (pk >= 0) src[i] = a.queries + (int64_t)(pk >> 4) * D + col;
                 } else {
-                    if (k + 0 < D) v.x = src[i][k0 + 0];
-                    if (k + 1 < D) v.y = src[i][k0 + 1];
-                    if (k + 2 < D) v.z = src[i][k0 + 2];
-                    if (k + 3 < D) v.w = src[i][k0 + 3];
+                    const int rid = s_rid[r - BQ];
+                    if (rid >= 0) src[i] = a.bank + (int64_t)rid * D + col;
                 }
             }
-            pre[i] = v;
         }
-    };
-    const int64_t KT = (D + BK - 1) / BK;
-    gload(0);
-    for (int64_t kt = 0; kt < KT; ++kt) {
+        f32x16 acc[QT];
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int f = tid + i * IVF_THREADS;
-            if (f < NV) *reinterpret_cast<float4*>(smem + (f >> 3) * LDS_STRIDE + (f & 7) * 4) = pre[i];
-        }
-        __syncthreads();
-        if (kt + 1 < KT) gload((kt + 1) * BK);
-        const float* qrow = Qs + li * LDS_STRIDE + 4 * lh;
-        const float* brow = Bs + (wave * 32 + li) * LDS_STRIDE + 4 * lh;
+        for (int t = 0; t < QT; ++t)
 #pragma unroll
-        for (int kk = 0; kk < BK / 8; ++kk) {
-            const float4 av = *reinterpret_cast<const float4*>(qrow + kk * 8);
-            const float4 bv = *reinterpret_cast<const float4*>(brow + kk * 8);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
-        }
-        __syncthreads();
-    }
-    // epilogue: lane = list slot (wave*32 + li) x 16 queries of the tile
-    const int slot = wave * 32 + li;
-    const int rid = s_rid[slot];
-    if (rid < 0) return;
-    const float inv_m = a.inv_norm[rid];
-    const float4 m = *reinterpret_cast<const float4*>(a.meta + (int64_t)rid * 4);
-    const float tw = 0.2f * expf(-(a.now - m.y) / 3600.0f);
+            for (int e = 0; e < 16; ++e) acc[t][e] = 0.0f;
+        // one k-tile of loads in flight per workgroup; several workgroups per CU overlap each
+        // other's waits (a second register set of loads in flight measured slower)
+        float4 pre[NLD];
+        auto gload = [&](int64_t k0) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int pk = s_q[(e & 3) + 8 * (e >> 2) + 4 * lh];
-        if (pk < 0) continue;
-        const int q = pk >> 4, p = pk & 15;
-        const float sim = acc[e] * a.inv_q[q] * inv_m;
-        const float comb = (0.5f * sim + tw) * m.x;
-        const int dst = a.qbase[q * 8 + p] + g * BR + slot;
-        if (dst < a.cap) {
-            a.cand_scores[(int64_t)q * a.cap + dst] = comb;
-            a.cand_idx[(int64_t)q * a.cap + dst] = rid;
+            for (int i = 0; i < NLD; ++i) {
+                const int f = tid + i * IVF_THREADS;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (f < NV && src[i]) {
+                    const int64_t k = k0 + (f & 7) * 4;
+                    if (VEC4) {
+                        if (k < D) v = *reinterpret_cast<const float4*>(src[i] + k0);
+                    } else {
+                        if (k + 0 < D) v.x = src[i][k0 + 0];
+                        if (k + 1 < D) v.y = src[i][k0 + 1];
+                        if (k + 2 < D) v.z = src[i][k0 + 2];
+                        if (k + 3 < D) v.w = src[i][k0 + 3];
+                    }
+                }
+                pre[i] = v;
+            }
+        };
+        gload(0);
+        for (int64_t kt = 0; kt < KT; ++kt) {
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                const int f = tid + i * IVF_THREADS;
+                if (f < NV) *reinterpret_cast<float4*>(smem + (f >> 3) * LDS_STRIDE + (f & 7) * 4) = pre[i];
+            }
+            __syncthreads();
+            if (kt + 1 < KT) gload((kt + 1) * BK);
+            const float* qrow = Qs + li * LDS_STRIDE + 4 * lh;
+            const float* brow = Bs + (wave * 32 + li) * LDS_STRIDE + 4 * lh;
+#pragma unroll
+            for (int kk = 0; kk < BK / 8; ++kk) {
+                const float4 bv = *reinterpret_cast<const float4*>(brow + kk * 8);
+#pragma unroll
+                for (int t = 0; t < QT; ++t) {
+                    const float4 av = *reinterpret_cast<const float4*>(qrow + t * 32 * LDS_STRIDE + kk * 8);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[t], 0, 0, 0);
+                }
+            }
+            __syncthreads();
         }
+        // epilogue: lane = list slot (wave*32 + li) x 16 queries of the tile
+        const int slot = wave * 32 + li;
+        const int rid = s_rid[slot];
+        if (rid >= 0) {
+            const float inv_m = a.inv_norm[rid];
+            const float4 m = *reinterpret_cast<const float4*>(a.meta + (int64_t)rid * 4);
+            const float tw = 0.2f * expf(-(a.now - m.y) / 3600.0f);
+#pragma unroll
+            for (int t = 0; t < QT; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int pk = s_q[t * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh];
+                if (pk < 0) continue;
+                const int q = pk >> 4, p = pk & 15;
+                const float sim = acc[t][e] * a.inv_q[q] * inv_m;
+                const float comb = (0.5f * sim + tw) * m.x;
+                const int dst = a.qbase[q * 8 + p] + g * BR + slot;
+                if (dst < a.cap) {
+                    a.cand_scores[(int64_t)q * a.cap + dst] = comb;
+                    a.cand_idx[(int64_t)q * a.cap + dst] = rid;
+                }
+            }
+        }
+        __syncthreads();   // s_q / s_rid / s_item are rewritten by the next item
     }
 }
 
@@ -1802,18 +1822,19 @@ int aura_knn_search(const float* bank, const float* inv_norm, const float* meta,
                               nullptr, nullptr, 0, stream);
 }
 
-// workspace of the IVF path (fixed candidate capacity per query; overflow -> caller falls back)
-constexpr int IVF_CAP = 16384;
+// workspace of the IVF path: `cap` candidate slots per query (the caller sizes it from the list
+// lengths: the 8 longest lists bound any query's candidates; a larger need sets the overflow flag)
+constexpr int IVF_SEL_CHUNK = 2048;
 
 struct IvfWorkspace {
     float* inv_q; int32_t* cnt; uint32_t* probe; float* probe_dist; int32_t* probe_ids; int32_t* qbase;
-    int32_t* lq_cnt; int32_t* lq_list; int32_t* grp_off;
+    int32_t* lq_cnt; int32_t* lq_list; int32_t* item_off; int32_t* work_counter;
     float* cand_scores; int32_t* cand_idx; float* cand2_scores; int32_t* cand2_idx;
-    int cap2;
+    int cap2, qp;
     int64_t bytes;
 };
 
-static IvfWorkspace carve_ivf(void* base, int k) {
+static IvfWorkspace carve_ivf(void* base, int64_t nq, int k, int cap) {
     IvfWorkspace w;
     char* p = static_cast<char*>(base);
     int64_t off = 0;
@@ -1822,90 +1843,105 @@ static IvfWorkspace carve_ivf(void* base, int k) {
         off += align_up(bytes, 256);
         return r;
     };
-    w.inv_q = reinterpret_cast<float*>(take(IVF_MAXQ * 4));
-    w.cnt = reinterpret_cast<int32_t*>(take((int64_t)IVF_MAXQ * CNT_STRIDE * 4));
-    w.probe = reinterpret_cast<uint32_t*>(take(IVF_MAXQ * 32));
-    w.probe_dist = reinterpret_cast<float*>(take((int64_t)IVF_MAXQ * 256 * 4));
-    w.probe_ids = reinterpret_cast<int32_t*>(take(IVF_MAXQ * 8 * 4));
-    w.qbase = reinterpret_cast<int32_t*>(take(IVF_MAXQ * 8 * 4));
+    const int64_t qp = nq < IVF_MAXQ ? (nq > 0 ? nq : 1) : IVF_MAXQ;
+    w.qp = (int)qp;
+    w.inv_q = reinterpret_cast<float*>(take(qp * 4));
+    w.cnt = reinterpret_cast<int32_t*>(take(qp * CNT_STRIDE * 4));
+    w.probe = reinterpret_cast<uint32_t*>(take(qp * 32));
+    w.probe_dist = reinterpret_cast<float*>(take(qp * 256 * 4));
+    w.probe_ids = reinterpret_cast<int32_t*>(take(qp * 8 * 4));
+    w.qbase = reinterpret_cast<int32_t*>(take(qp * 8 * 4));
     w.lq_cnt = reinterpret_cast<int32_t*>(take(256 * 4));
     w.lq_list = reinterpret_cast<int32_t*>(take((int64_t)256 * IVF_MAXQ * 4));
-    w.grp_off = reinterpret_cast<int32_t*>(take(257 * 4));
-    w.cand_scores = reinterpret_cast<float*>(take((int64_t)IVF_MAXQ * IVF_CAP * 4));
-    w.cand_idx = reinterpret_cast<int32_t*>(take((int64_t)IVF_MAXQ * IVF_CAP * 4));
-    w.cap2 = (int)align_up((int64_t)(IVF_CAP / 2048) * k, 64);
-    w.cand2_scores = reinterpret_cast<float*>(take((int64_t)IVF_MAXQ * w.cap2 * 4));
-    w.cand2_idx = reinterpret_cast<int32_t*>(take((int64_t)IVF_MAXQ * w.cap2 * 4));
+    w.item_off = reinterpret_cast<int32_t*>(take(257 * 4));
+    w.work_counter = reinterpret_cast<int32_t*>(take(16));
+    w.cand_scores = reinterpret_cast<float*>(take(qp * cap * 4));
+    w.cand_idx = reinterpret_cast<int32_t*>(take(qp * cap * 4));
+    w.cap2 = (int)align_up((int64_t)(cap / IVF_SEL_CHUNK) * k, 64);
+    w.cand2_scores = reinterpret_cast<float*>(take(qp * w.cap2 * 4));
+    w.cand2_idx = reinterpret_cast<int32_t*>(take(qp * w.cap2 * 4));
     w.bytes = off;
     return w;
 }
 
-int64_t aura_knn_ivf_workspace_bytes(int k) {
-    if (k <= 0 || k > SEL_MAX_K) return AURA_E_INVAL;
-    return carve_ivf(nullptr, k).bytes;
+static bool ivf_cap_ok(int k, int cap) {
+    return cap >= IVF_SEL_CHUNK && cap % IVF_SEL_CHUNK == 0 &&
+           (int64_t)(cap / IVF_SEL_CHUNK) * k <= SEL_LDS_KEYS_HARD;
+}
+
+int64_t aura_knn_ivf_workspace_bytes(int64_t nq, int k, int cap) {
+    if (nq < 0 || k <= 0 || k > SEL_MAX_K || !ivf_cap_ok(k, cap)) return AURA_E_INVAL;
+    return carve_ivf(nullptr, nq, k, cap).bytes;
 }
 
 int aura_knn_search_ivf(const float* bank, const float* inv_norm, const float* meta,
                         const float* queries, float now, int64_t N, int64_t D, int64_t nq, int k,
                         const float* centroids, int nprobe, const int32_t* list_rows,
-                        const int32_t* list_off, const int32_t* list_len, int32_t idx_base,
+                        const int32_t* list_off, const int32_t* list_len, int cap, int32_t idx_base,
                         float* out_scores, int32_t* out_idx, void* workspace,
                         int64_t workspace_bytes, int32_t* overflow_out, void* stream) {
     if (N <= 0 || D <= 0 || nq < 0 || k <= 0 || k > SEL_MAX_K) return AURA_E_INVAL;
-    if (nprobe <= 0 || nprobe > 8) return AURA_E_INVAL;
+    if (nprobe <= 0 || nprobe > 8 || !ivf_cap_ok(k, cap)) return AURA_E_INVAL;
     if (nq == 0) return AURA_OK;
     if (!bank || !inv_norm || !meta || !queries || !centroids || !list_rows || !list_off ||
         !list_len || !out_scores || !out_idx || !workspace)
         return AURA_E_INVAL;
     if (reinterpret_cast<uintptr_t>(meta) & 15) return AURA_E_ALIGN;
     if (reinterpret_cast<uintptr_t>(workspace) & 255) return AURA_E_ALIGN;
-    const IvfWorkspace w = carve_ivf(workspace, k);
+    const IvfWorkspace w = carve_ivf(workspace, nq, k, cap);
     if (w.bytes > workspace_bytes) return AURA_E_INVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     int rc;
-    const size_t lds = (size_t)(32 + IVF_GROUP) * LDS_STRIDE * sizeof(float);
     const bool vec4 = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(bank) & 15) == 0) &&
                       ((reinterpret_cast<uintptr_t>(queries) & 15) == 0);
-    const int64_t max_groups = (N + IVF_GROUP - 1) / IVF_GROUP + 256;
+    // persistent grid: 6 workgroups of 256 threads fit a CU (LDS 23 KiB, 78 VGPRs)
+    const dim3 grid((unsigned)(device_cu_count() * 6));
 
-    for (int64_t qb0 = 0; qb0 < nq; qb0 += IVF_MAXQ) {
-        const int nqb = (int)((nq - qb0) < IVF_MAXQ ? (nq - qb0) : IVF_MAXQ);
+    for (int64_t qb0 = 0; qb0 < nq; qb0 += w.qp) {
+        const int nqb = (int)((nq - qb0) < w.qp ? (nq - qb0) : w.qp);
         const float* qptr = queries + qb0 * D;
+        // expected queries per list = nqb * nprobe / 256: 64-query tiles once that reaches ~48
+        const int qt = (int64_t)nqb * nprobe >= 48 * 256 ? 2 : 1;
         hipLaunchKernelGGL(query_prep_kernel, dim3((unsigned)((nqb + 3) / 4)), dim3(256), 0, s, qptr,
                            w.inv_q, (int64_t)nqb, D, qb0 == 0 ? overflow_out : nullptr);
         if ((rc = check_launch())) return rc;
         if ((rc = launch_probe(centroids, qptr, D, nqb, nprobe, w.probe_dist, w.probe, w.probe_ids, s)))
             return rc;
         hipLaunchKernelGGL(ivf_prepare_kernel, dim3(1), dim3(256), 0, s, w.probe_ids, nprobe, nqb,
-                           list_len, w.lq_cnt, w.lq_list, w.qbase, w.cnt, w.grp_off, IVF_CAP,
-                           overflow_out);
+                           list_len, w.lq_cnt, w.lq_list, w.qbase, w.cnt, w.item_off, w.work_counter,
+                           cap, qt * 32, overflow_out);
         if ((rc = check_launch())) return rc;
 
         IvfArgs a{};
         a.bank = bank; a.inv_norm = inv_norm; a.meta = meta; a.queries = qptr; a.inv_q = w.inv_q;
         a.list_rows = list_rows; a.list_off = list_off; a.list_len = list_len;
-        a.lq_cnt = w.lq_cnt; a.lq_list = w.lq_list; a.qbase = w.qbase; a.grp_off = w.grp_off;
-        a.cand_scores = w.cand_scores; a.cand_idx = w.cand_idx; a.cap = IVF_CAP;
+        a.lq_cnt = w.lq_cnt; a.lq_list = w.lq_list; a.qbase = w.qbase;
+        a.item_off = w.item_off; a.work_counter = w.work_counter;
+        a.cand_scores = w.cand_scores; a.cand_idx = w.cand_idx; a.cap = cap;
         a.now = now; a.D = D; a.nq = nqb;
-        const dim3 grid((unsigned)max_groups, (unsigned)((nqb + 31) / 32));
         const bool prof = g_prof.on && g_prof.used < g_prof.cap;
         if (prof) {
             (void)hipEventRecord(g_prof.start[g_prof.used], s);
             g_prof.rows = N; g_prof.nq = nqb;
         }
-        if (vec4) hipLaunchKernelGGL(ivf_scan_kernel<true>, grid, dim3(IVF_THREADS), lds, s, a);
-        else hipLaunchKernelGGL(ivf_scan_kernel<false>, grid, dim3(IVF_THREADS), lds, s, a);
+        const size_t lds = (size_t)(32 * qt + IVF_GROUP) * LDS_STRIDE * sizeof(float);
+        if (qt == 2) {
+            if (vec4) hipLaunchKernelGGL((ivf_scan_kernel<true, 2>), grid, dim3(IVF_THREADS), lds, s, a);
+            else hipLaunchKernelGGL((ivf_scan_kernel<false, 2>), grid, dim3(IVF_THREADS), lds, s, a);
+        } else {
+            if (vec4) hipLaunchKernelGGL((ivf_scan_kernel<true, 1>), grid, dim3(IVF_THREADS), lds, s, a);
+            else hipLaunchKernelGGL((ivf_scan_kernel<false, 1>), grid, dim3(IVF_THREADS), lds, s, a);
+        }
         if ((rc = check_launch())) return rc;
         if (prof) (void)hipEventRecord(g_prof.stop[g_prof.used++], s);
 
         // exact top-k of each query's slots (count = total length of its probed lists), in two
         // levels: 2048-slot chunks keep their k best (many small workgroups, 16 KiB of LDS each),
         // then one sorted select over the chunk winners
-        constexpr int IVF_SEL_CHUNK = 2048;
-        const int64_t nch = IVF_CAP / IVF_SEL_CHUNK;
+        const int64_t nch = cap / IVF_SEL_CHUNK;
         SelectArgs r{};
-        r.src_scores = w.cand_scores; r.src_idx = w.cand_idx; r.src_qs = IVF_CAP; r.src_inner = IVF_CAP;
-        r.src_outer = 0; r.src_cnt = w.cnt; r.n_max = IVF_CAP; r.chunk = IVF_SEL_CHUNK; r.blk = 1; r.step = 1;
+        r.src_scores = w.cand_scores; r.src_idx = w.cand_idx; r.src_qs = cap; r.src_inner = cap;
+        r.src_outer = 0; r.src_cnt = w.cnt; r.n_max = cap; r.chunk = IVF_SEL_CHUNK; r.blk = 1; r.step = 1;
         r.row_begin = 0; r.row_end = N; r.k = k; r.sorted = 0;
         r.dst_scores = w.cand2_scores; r.dst_idx = w.cand2_idx; r.dst_qs = w.cap2; r.dst_off = 0;
         if ((rc = launch_select(r, nch, nqb, s))) return rc;

@@ -249,8 +249,15 @@ def knn_search(bank, inv_norm, meta, queries, k: int, now: float, count: Optiona
     return out_s, out_i
 
 
+def ivf_capacity(longest_lists_total: int, k: int) -> Optional[int]:
+    """Candidate slots per query for the IVF recall: the sum of the nprobe longest lists rounded
+    up to 2048; None if the two-level select cannot hold it ((cap/2048)*k must be <= 16384)."""
+    cap = max(2048, (int(longest_lists_total) + 2047) // 2048 * 2048)
+    return cap if (cap // 2048) * k <= 16384 else None
+
+
 def knn_search_ivf(bank, inv_norm, meta, queries, k: int, now: float, count: int, centroids,
-                   nprobe: int, list_rows, list_off, list_len, idx_base: int = 0
+                   nprobe: int, list_rows, list_off, list_len, cap: int, idx_base: int = 0
                    ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """Inverted-list recall over rows [0, count): (scores [nq, k], idx [nq, k], overflow flag [1]).
     The flag is a device tensor (non-zero: some query's probed lists exceed the slot capacity and
@@ -279,11 +286,13 @@ def knn_search_ivf(bank, inv_norm, meta, queries, k: int, now: float, count: int
     if nq == 0:
         return out_s, out_i, ovf
     L = lib()
-    nbytes = L.aura_knn_ivf_workspace_bytes(k)
+    nbytes = L.aura_knn_ivf_workspace_bytes(nq, k, cap)
+    if nbytes < 0:
+        raise ValueError(f"knn_search_ivf: capacity {cap} is not usable with k={k}")
     ws = _workspace(dev, nbytes)
     base = (ws.data_ptr() + 255) // 256 * 256
     check(L.aura_knn_search_ivf(_p(bank), _p(inv_norm), _p(meta), _p(queries), now, count, D, nq, k,
-                                _p(centroids), nprobe, _p(list_rows), _p(list_off), _p(list_len),
+                                _p(centroids), nprobe, _p(list_rows), _p(list_off), _p(list_len), cap,
                                 idx_base, _p(out_s), _p(out_i), base, nbytes, _p(ovf), _stream()),
           "aura_knn_search_ivf")
     return out_s, out_i, ovf

@@ -161,8 +161,10 @@ def centroid_index_recall(dev, bank, inv, meta, q, k, now, steps=30):
     off = torch.cat([torch.zeros(1, dtype=torch.int32, device=dev),
                      torch.cumsum(lens, 0).to(torch.int32)]).contiguous()
 
+    cap = ops.ivf_capacity(int(torch.topk(lens, 8).values.sum().item()), k)
+
     def step():
-        return ops.knn_search_ivf(bank, inv, meta_i, q, k, now, N, cent, 8, order, off, lens)
+        return ops.knn_search_ivf(bank, inv, meta_i, q, k, now, N, cent, 8, order, off, lens, cap)
     s_i, r_i, ovf = step()
     # agreement with the masked full scan (same candidate sets): must be identical
     s_m, r_m = ops.knn_search(bank, inv, meta_i, q, k, now, count=N, centroids=cent, nprobe=8)

@@ -141,19 +141,21 @@ int aura_knn_search_ex(const float* bank, const float* inv_norm, const float* me
 
 /* Inverted-list (IVF) form of the centroid-candidate recall: identical results to
  * aura_knn_search_ex(..., centroids, nprobe) without a location term, but each probed list is
- * streamed once per query batch and only against the queries that probe it.  list_rows: row ids
- * of bank[0..N) grouped by centroid id (int32 [N], rows with centroid id < 0 first);
- * list_off [257]: start of each list in list_rows (list_off[256] = N); list_len [256].
+ * streamed once per pass of up to 2048 queries and only against the queries that probe it.
+ * list_rows: row ids of bank[0..N) grouped by centroid id (int32 [N], rows with centroid id < 0
+ * first); list_off [257]: start of each list in list_rows (list_off[256] = N); list_len [256].
  * The host module derives the three arrays from meta[.][2] after writes / rebuilds.  nprobe <= 8.
- * A query whose lists hold more than 16384 rows sets *overflow_out (the caller falls back to the
- * masked full scan).  workspace: aura_knn_ivf_workspace_bytes(k) bytes.
+ * cap: candidate slots per query, a multiple of 2048 with (cap/2048)*k <= 16384; the sum of the
+ * nprobe longest lists never overflows it.  A query whose lists hold more rows sets *overflow_out
+ * (the caller falls back to the masked full scan).
+ * workspace: aura_knn_ivf_workspace_bytes(nq, k, cap) bytes.
  * Replaces retrieve_similar_memories steps 0-5, src/core/hippocampal.py:259-307. */
-int64_t aura_knn_ivf_workspace_bytes(int k);
+int64_t aura_knn_ivf_workspace_bytes(int64_t nq, int k, int cap);
 int aura_knn_search_ivf(const float* bank, const float* inv_norm, const float* meta,
                         const float* queries, float now, int64_t N, int64_t D, int64_t nq, int k,
                         const float* centroids, int nprobe, const int32_t* list_rows,
-                        const int32_t* list_off, const int32_t* list_len, int32_t idx_base,
-                        float* out_scores, int32_t* out_idx, void* workspace,
+                        const int32_t* list_off, const int32_t* list_len, int cap,
+                        int32_t idx_base, float* out_scores, int32_t* out_idx, void* workspace,
                         int64_t workspace_bytes, int32_t* overflow_out, void* stream);
 
 /* Measurement hooks (bench.py): between aura_profile_begin(max) and aura_profile_end, every

@@ -97,8 +97,13 @@ def kmeans_update(bank, assign, centroids, k, counts=None, meta=None, update_mea
         meta[:n, 2] = assign.float()
 
 
+def ivf_capacity(longest_lists_total, k):
+    cap = max(2048, (int(longest_lists_total) + 2047) // 2048 * 2048)
+    return cap if (cap // 2048) * k <= 16384 else None
+
+
 def knn_search_ivf(bank, inv_norm, meta, queries, k, now, count, centroids, nprobe, list_rows, list_off,
-                   list_len, idx_base=0):
+                   list_len, cap, idx_base=0):
     # host-logic stand-in: the lists must describe the same candidate sets as the mask
     n = count
     assert int(list_off[256]) == n and int(list_len.sum()) == int((meta[:n, 2] >= 0).sum())

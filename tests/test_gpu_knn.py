@@ -336,7 +336,8 @@ def test_memory_ops_match_reference_layer_loop(dev, monkeypatch):
     assert z.abs().sum() == 0 and zs.abs().sum() == 0
 
 
-@pytest.mark.parametrize("N,D,nq,k", [(3000, 32, 12, 7), (50_000, 128, 256, 32), (20_000, 64, 300, 5)])
+@pytest.mark.parametrize("N,D,nq,k", [(3000, 32, 12, 7), (50_000, 128, 256, 32), (20_000, 64, 300, 5),
+                                      (30_000, 64, 1700, 8)])     # >= 1536 queries: 64-query tiles
 def test_ivf_equals_masked_full_scan(dev, N, D, nq, k):
     """The inverted-list recall returns bit-identical scores/rows to the masked full scan (same
     candidate sets, same arithmetic) and matches the oracle's candidate path."""
