@@ -91,6 +91,17 @@ __device__ __forceinline__ float round_bf16(float x) {
     return static_cast<float>(static_cast<__bf16>(x));
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// two roundings for the price of one convert: v_cvt_pk_bf16_f32 packs both results
+__device__ __forceinline__ void round_bf16_pair(float& a, float& b) {
+    const f32x2 f = {a, b};
+    const f32x2 g = __builtin_convertvector(__builtin_convertvector(f, bf16x2), f32x2);
+    a = g.x;
+    b = g.y;
+}
+
 // src/core/language_zone/gif_neuron.py:56-67.  BF16 = state and every intermediate are bf16
 // tensors in the reference, i.e. each op rounds its fp32 result to bf16.
 template <bool BF16>
@@ -99,7 +110,34 @@ struct GifModel {
     static constexpr int NS = 2;
     struct Lane { float s0, s1; };
     __device__ __forceinline__ static float r(float x) { return BF16 ? round_bf16(x) : x; }
+    __device__ __forceinline__ static void r2(float& a, float& b) { if (BF16) round_bf16_pair(a, b); }
     __device__ __forceinline__ void init(Lane&, int64_t) const {}
+    // two neurons at once: the same op sequence as step(), roundings paired (bf16 build: 3 VALU
+    // ops per two roundings instead of 4).  x*2 of a bf16 value is exact, so r(r(L*theta)*2) is
+    // r(L*theta)*2.
+    __device__ __forceinline__ void step2(Lane& la, Lane& lb, float ia, float ib, float& sa,
+                                          float& sb) const {
+        float va = la.s0 * decay, vb = lb.s0 * decay;           r2(va, vb);
+        va = va + ia; vb = vb + ib;                               r2(va, vb);
+        float ca = Lf * la.s1, cb = Lf * lb.s1;                   r2(ca, cb);
+        ca = ca * 2.0f; cb = cb * 2.0f;
+        va = fminf(fmaxf(va, -ca), ca); vb = fminf(fmaxf(vb, -cb), cb);
+        float ta = la.s1 + 1e-6f, tb = lb.s1 + 1e-6f;             r2(ta, tb);
+        float na = va / ta, nb = vb / tb;                         r2(na, nb);
+        sa = fminf(fmaxf(floorf(na), 0.0f), Lf); sb = fminf(fmaxf(floorf(nb), 0.0f), Lf);
+        float pa = sa * la.s1, pb = sb * lb.s1;                   r2(pa, pb);
+        va = va - pa; vb = vb - pb;                               r2(va, vb);
+        float tha = la.s1, thb = lb.s1;
+        if (alpha > 0.0f) {
+            float ea = alpha * sa, eb = alpha * sb;               r2(ea, eb);
+            float ua = tha + ea, ub = thb + eb;                   r2(ua, ub);
+            float da = tha - thr0, db = thb - thr0;               r2(da, db);
+            da = alpha * da; db = alpha * db;                     r2(da, db);
+            tha = ua - da; thb = ub - db;                         r2(tha, thb);
+        }
+        la.s0 = va; la.s1 = tha;
+        lb.s0 = vb; lb.s1 = thb;
+    }
     __device__ __forceinline__ float step(Lane& l, float i_t) const {
         float v = l.s0, theta = l.s1;
         v = r(r(v * decay) + i_t);
@@ -114,6 +152,32 @@ struct GifModel {
         return spike;
     }
 };
+
+// step two neurons: models with a paired form use it, the others take two scalar steps
+template <class Model>
+__device__ __forceinline__ auto step_pair(const Model& m, typename Model::Lane& a,
+                                          typename Model::Lane& b, float xa, float xb, float& sa,
+                                          float& sb, int) -> decltype(m.step2(a, b, xa, xb, sa, sb)) {
+    m.step2(a, b, xa, xb, sa, sb);
+}
+template <class Model>
+__device__ __forceinline__ void step_pair(const Model& m, typename Model::Lane& a,
+                                          typename Model::Lane& b, float xa, float xb, float& sa,
+                                          float& sb, long) {
+    sa = m.step(a, xa);
+    sb = m.step(b, xb);
+}
+template <class Model, int VEC>
+__device__ __forceinline__ void step_vec(const Model& m, typename Model::Lane (&lane)[VEC],
+                                         const float (&x)[VEC], float (&spk)[VEC]) {
+    if constexpr (VEC % 2 == 0) {
+#pragma unroll
+        for (int e = 0; e < VEC; e += 2) step_pair(m, lane[e], lane[e + 1], x[e], x[e + 1], spk[e], spk[e + 1], 0);
+    } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) spk[e] = m.step(lane[e], x[e]);
+    }
+}
 
 // ------------------------------------------------------------------------------------------
 // 16-byte vector I/O
@@ -208,11 +272,9 @@ __global__ __launch_bounds__(256) void seq_rtc_kernel(Model m, const T* __restri
             float xin[VEC], spk[VEC];
             Io<T, VEC>::load(xp, xin);
             for (int64_t t = 0; t < Tn; ++t) {
+                step_vec<Model, VEC>(m, lane, xin, spk);
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) {
-                    spk[e] = m.step(lane[e], xin[e]);
-                    acc[e] += spk[e];
-                }
+                for (int e = 0; e < VEC; ++e) acc[e] += spk[e];
                 if (!MEAN_OUT) Io<T, VEC>::store(op + t * C, spk);
             }
         } else {
@@ -224,22 +286,18 @@ __global__ __launch_bounds__(256) void seq_rtc_kernel(Model m, const T* __restri
 #pragma unroll
                 for (int j = 0; j < RTC_UNROLL; ++j) {
                     float spk[VEC];
+                    step_vec<Model, VEC>(m, lane, xin[j], spk);
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) {
-                        spk[e] = m.step(lane[e], xin[j][e]);
-                        acc[e] += spk[e];
-                    }
+                    for (int e = 0; e < VEC; ++e) acc[e] += spk[e];
                     if (!MEAN_OUT) Io<T, VEC>::store(op + (t + j) * C, spk);
                 }
             }
             for (; t < Tn; ++t) {
                 float xin[VEC], spk[VEC];
                 Io<T, VEC>::load(xp + t * C, xin);
+                step_vec<Model, VEC>(m, lane, xin, spk);
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) {
-                    spk[e] = m.step(lane[e], xin[e]);
-                    acc[e] += spk[e];
-                }
+                for (int e = 0; e < VEC; ++e) acc[e] += spk[e];
                 if (!MEAN_OUT) Io<T, VEC>::store(op + t * C, spk);
             }
         }
