@@ -324,10 +324,10 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "r01_knn_pmc_per_dispatch.json")
         if os.path.exists(pmc) and args.bank_rows == 100_000 and world == 1:
             try:
-                d = json.load(open(pmc)).get("knn_scan_filter_v2<true>", {})
+                d = json.load(open(pmc)).get("knn_scan_filter_v2<true, true>", {})
                 if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
                     roof["traffic"] = (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0
-                    roof["traffic_source"] = "profiles/r01_knn_pmc_per_dispatch.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)"
+                    roof["traffic_source"] = "profiles/r01_pmc_per_dispatch.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)"
             except Exception:
                 pass
 
