@@ -24,6 +24,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "../../include/aura_hip.h"
 
 #pragma clang fp contract(off)
@@ -608,49 +610,58 @@ __global__ __launch_bounds__(SCAN_THREADS) void knn_scan_filter_v2(const ScanArg
         if (KT > 1) gload(BK);
         __syncthreads();
 
-        for (int64_t kt = 0; kt < KT; ++kt) {
-            const float* cur = (kt & 1) ? buf1 : buf0;
-            float* nxt = (kt & 1) ? buf0 : buf1;
-            const bool has1 = kt + 1 < KT, has2 = kt + 2 < KT;
-            const float* qrow = cur + (wave * 32 + li) * LDS_STRIDE + 4 * lh;
-            const float* brow = cur + (BQ + li) * LDS_STRIDE + 4 * lh;
+        // k loop, specialised on the number of real row tiles in the chunk (NT): a partial chunk
+        // issues only NT/4 of the MFMAs, so spans of 11 tiles (4+4+3) cost 11, not 12
+        auto kloop = [&](auto nt_tag) {
+            constexpr int NT = decltype(nt_tag)::value;
+            for (int64_t kt = 0; kt < KT; ++kt) {
+                const float* cur = (kt & 1) ? buf1 : buf0;
+                float* nxt = (kt & 1) ? buf0 : buf1;
+                const bool has1 = kt + 1 < KT, has2 = kt + 2 < KT;
+                const float* qrow = cur + (wave * 32 + li) * LDS_STRIDE + 4 * lh;
+                const float* brow = cur + (BQ + li) * LDS_STRIDE + 4 * lh;
 
-            if (wave < 4) {                 // early stagers
-                if (has1) lstore(nxt);
-                if (has2) gload((kt + 2) * BK);
-            }
-            float4 av[2], bv[2][RT];
-            av[0] = *reinterpret_cast<const float4*>(qrow);
-#pragma unroll
-            for (int r = 0; r < RT; ++r)
-                bv[0][r] = *reinterpret_cast<const float4*>(brow + r * 32 * LDS_STRIDE);
-#pragma unroll
-            for (int kk = 0; kk < BK / 8; ++kk) {
-                const int s0 = kk & 1, s1 = s0 ^ 1;
-                if (kk + 1 < BK / 8) {
-                    av[s1] = *reinterpret_cast<const float4*>(qrow + (kk + 1) * 8);
-#pragma unroll
-                    for (int r = 0; r < RT; ++r)
-                        bv[s1][r] = *reinterpret_cast<const float4*>(brow + r * 32 * LDS_STRIDE +
-                                                                     (kk + 1) * 8);
-                }
-                const float af[4] = {av[s0].x, av[s0].y, av[s0].z, av[s0].w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-#pragma unroll
-                    for (int r = 0; r < RT; ++r) {
-                        const float bf = j == 0 ? bv[s0][r].x : j == 1 ? bv[s0][r].y
-                                         : j == 2 ? bv[s0][r].z : bv[s0][r].w;
-                        acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j], bf, acc[r], 0, 0, 0);
-                    }
-                }
-                if (kk == 0 && wave >= 4) {  // late stagers: after their first 16 MFMAs
+                if (wave < 4) {                 // early stagers
                     if (has1) lstore(nxt);
                     if (has2) gload((kt + 2) * BK);
                 }
+                float4 av[2], bv[2][NT];
+                av[0] = *reinterpret_cast<const float4*>(qrow);
+#pragma unroll
+                for (int r = 0; r < NT; ++r)
+                    bv[0][r] = *reinterpret_cast<const float4*>(brow + r * 32 * LDS_STRIDE);
+#pragma unroll
+                for (int kk = 0; kk < BK / 8; ++kk) {
+                    const int s0 = kk & 1, s1 = s0 ^ 1;
+                    if (kk + 1 < BK / 8) {
+                        av[s1] = *reinterpret_cast<const float4*>(qrow + (kk + 1) * 8);
+#pragma unroll
+                        for (int r = 0; r < NT; ++r)
+                            bv[s1][r] = *reinterpret_cast<const float4*>(brow + r * 32 * LDS_STRIDE +
+                                                                         (kk + 1) * 8);
+                    }
+                    const float af[4] = {av[s0].x, av[s0].y, av[s0].z, av[s0].w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                        for (int r = 0; r < NT; ++r) {
+                            const float bf = j == 0 ? bv[s0][r].x : j == 1 ? bv[s0][r].y
+                                             : j == 2 ? bv[s0][r].z : bv[s0][r].w;
+                            acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j], bf, acc[r], 0, 0, 0);
+                        }
+                    }
+                    if (kk == 0 && wave >= 4) {  // late stagers: after their first MFMA group
+                        if (has1) lstore(nxt);
+                        if (has2) gload((kt + 2) * BK);
+                    }
+                }
+                __syncthreads();
             }
-            __syncthreads();
-        }
+        };
+        if (nt == 4) kloop(std::integral_constant<int, 4>{});
+        else if (nt == 3) kloop(std::integral_constant<int, 3>{});
+        else if (nt == 2) kloop(std::integral_constant<int, 2>{});
+        else kloop(std::integral_constant<int, 1>{});
 
         // ---- epilogue: combined score + candidate append (same arithmetic as knn_scan_kernel) ----
         uint32_t* s_mask = reinterpret_cast<uint32_t*>(smem);
@@ -1717,6 +1728,8 @@ int aura_knn_search_ex(const float* bank, const float* inv_norm, const float* me
         int64_t floor_rows = N / 8 < 8192 ? N / 8 : 8192;
         if (floor_rows < (int64_t)k * 48) floor_rows = (int64_t)k * 48;
         if (sample_rows < floor_rows) sample_rows = floor_rows;
+        // (growing the sample so that every span loses a tile made the scan 7 % faster but pushed the
+        //  sample pass past one workgroup per CU: net slower, 0.449 vs 0.433 ms per step)
         const int64_t n_sample_tiles = (sample_rows + br - 1) / br;
         const bool dense_all = (flags & AURA_KNN_FORCE_DENSE) || n_sample_tiles * 4 > ntiles ||
                                n_sample_tiles * br > DENSE_COLS ||
