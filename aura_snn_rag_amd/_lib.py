@@ -47,6 +47,11 @@ SIGNATURES = {
     "aura_kmeans_assign": (I, [P, P, P, P, I64, I64, I, P]),
     "aura_kmeans_update": (I, [P, P, P, P, P, I64, I64, I, I, P]),
     "aura_addition_linear": (I, [P, P, P, P, I64, I64, I64, P]),
+    "aura_gif_train_forward": (I, [P, P, P, P, P, P, F, I, F, F, I64, I64, I64, P]),
+    "aura_gif_backward": (I, [P, P, P, P, P, P, F, I, F, F, I64, I64, I64, P]),
+    "aura_lif_train_forward": (I, [P, P, P, P, P, P, P, I64, I64, P]),
+    "aura_lif_backward": (I, [P, P, P, P, P, P, P, P, P, I64, I64, P]),
+    "aura_gif_prosody_run": (I, [P, P, P, P, P, F, I, F, F, F, I64, I64, I64, P]),
     "aura_profile_begin": (I, [I]),
     "aura_profile_end": (I, [P, I]),
     "aura_profile_last_scan": (I, [P, P]),

@@ -26,9 +26,8 @@ from .. import ops
 def _no_grad_input(x: torch.Tensor, who: str) -> None:
     if x.requires_grad and torch.is_grad_enabled():
         raise NotImplementedError(
-            f"{who}: the HIP forward does not record autograd history yet (surrogate-gradient "
-            f"backward kernels are not implemented); call it under torch.no_grad() or detach the "
-            f"input.")
+            f"{who}: this HIP loop does not record autograd history; call it under "
+            f"torch.no_grad() or detach the input.")
 
 
 def _as_f32_input(x: torch.Tensor, who: str) -> torch.Tensor:
@@ -167,6 +166,34 @@ class AdExNeuron(nn.Module):
         return self.forward_sequence(I)
 
 
+class LifStepFunction(torch.autograd.Function):
+    """One differentiable LIF step: (x, mem, beta, threshold, slope) -> (spk, mem_out); backward is
+    ``LearnableSurrogateGradient.backward`` of the reference (``neuron.py:80-108``) fused with the
+    membrane recurrence, as ``aura_lif_backward``."""
+
+    @staticmethod
+    def forward(ctx, x, mem, beta, threshold, slope):
+        shape = x.shape
+        size = shape[-1]
+        x2 = x.contiguous().view(-1, size)
+        m2 = mem.detach().contiguous().view(-1, size)
+        spk, mem_out, pre = torch.empty_like(x2), torch.empty_like(x2), torch.empty_like(x2)
+        ops.lif_train_forward(x2, m2, beta, threshold, spk, mem_out, pre)
+        ctx.save_for_backward(pre, beta, threshold, slope.detach())
+        ctx.shape = shape
+        return spk.view(shape), mem_out.view(shape)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_spk, g_mem):
+        pre, beta, threshold, slope = ctx.saved_tensors
+        size = pre.shape[-1]
+        g_x, g_prev, raw = torch.empty_like(pre), torch.empty_like(pre), torch.empty_like(pre)
+        ops.lif_backward(pre, g_spk.contiguous().view(-1, size), g_mem.contiguous().view(-1, size),
+                         beta, threshold, slope.contiguous(), g_x, g_prev, raw)
+        return g_x.view(ctx.shape), g_prev.view(ctx.shape), None, None, raw.sum(dim=0)
+
+
 class VectorizedLIFNeuron(nn.Module):
     """One LIF step per call on ``[..., size]`` input; returns ``(spk, mem)``
     (``neuron.py:115-139``).  ``forward_sequence`` runs a whole ``[B, T, size]`` sequence in one
@@ -194,10 +221,25 @@ class VectorizedLIFNeuron(nn.Module):
             raise ValueError(f"VectorizedLIFNeuron(size={self.size}): last dim is {x.shape[-1]}")
         return x
 
+    def _wants_grad(self, x: torch.Tensor) -> bool:
+        return torch.is_grad_enabled() and (x.requires_grad or self.slope.requires_grad or
+                                            (self.mem is not None and self.mem.requires_grad))
+
     def forward(self, input_: torch.Tensor):
+        if self._wants_grad(input_):
+            _as_f32_input(input_, "VectorizedLIFNeuron")             # device / dtype checks only
+            x = input_
+            if x.shape[-1] != self.size:
+                raise ValueError(f"VectorizedLIFNeuron(size={self.size}): last dim is {x.shape[-1]}")
+            if self.mem is None or self.mem.shape != x.shape:
+                self.mem = torch.zeros_like(x)
+            spk, self.mem = LifStepFunction.apply(x, self.mem, self.beta, self.threshold, self.slope)
+            return spk, self.mem
         x = self._prep(input_)
         if self.mem is None or self.mem.shape != x.shape:
             self.mem = torch.zeros_like(x)
+        elif self.mem.requires_grad:
+            self.mem = self.mem.detach().clone()
         spk = torch.empty_like(x)
         rows = x.numel() // self.size if self.size else 0
         ops.lif_run(x.view(rows, 1, self.size), spk.view(rows, 1, self.size),
@@ -211,6 +253,8 @@ class VectorizedLIFNeuron(nn.Module):
         B, T, _ = x.shape
         if self.mem is None or self.mem.shape != (B, self.size):
             self.mem = torch.zeros(B, self.size, device=x.device, dtype=x.dtype)
+        elif self.mem.requires_grad:
+            self.mem = self.mem.detach().clone()
         spikes = torch.empty_like(x)
         ops.lif_run(x, spikes, self.mem, self.beta, self.threshold)
         return spikes

@@ -96,7 +96,8 @@ class EnhancedSpikingNeuron(nn.Module):
             return self.core.forward_sequence(x_eff.unsqueeze(1)).squeeze(1), {}, {}
         if is_seq:
             return self.core.forward_sequence(x_eff), None, {}
-        spikes, mem = self.core(x_eff)
+        with torch.no_grad():                       # the zone is a forward-only path
+            spikes, mem = self.core(x_eff)
         return spikes, mem, {}
 
 

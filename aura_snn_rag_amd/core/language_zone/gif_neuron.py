@@ -10,7 +10,11 @@ The T-step Python loop of the reference (``gif_neuron.py:54-69``, eight eager op
 registers.  The dense ``nn.Linear`` stays a library GEMM on the matrix cores.  fp32 and bf16; in
 bf16 each op rounds to bf16 exactly as the reference's bf16 tensors do.
 
-Forward only (no autograd through the spike function yet; see ``MultiBitSurrogate``).
+Training: when autograd is recording (grad mode on and the input, a parameter or the state
+requires grad) the fp32 loop runs as ``aura_gif_train_forward`` and its gradient as
+``aura_gif_backward`` -- BPTT through the T steps with the triangular surrogate of
+``MultiBitSurrogate`` -- wrapped in ``GifLoopFunction``; the ``nn.Linear`` around it is ordinary
+autograd.  bf16 is inference-only.
 """
 from __future__ import annotations
 
@@ -47,10 +51,61 @@ def _check_input(x: torch.Tensor, who: str) -> None:
     if not x.is_cuda:
         raise ops.AuraDeviceError(f"{who}: input is on {x.device}; the GIF loop runs only as a HIP "
                                   f"kernel (no CPU fallback)")
-    if x.requires_grad and torch.is_grad_enabled():
-        raise NotImplementedError(f"{who}: forward-only HIP path; call under torch.no_grad()")
     if x.dtype not in (torch.float32, torch.bfloat16):
         raise TypeError(f"{who}: fp32 or bf16 expected, got {x.dtype}")
+
+
+def wants_grad(module: nn.Module, x: torch.Tensor, state=None) -> bool:
+    """True when the reference would record autograd history for this call."""
+    if not torch.is_grad_enabled():
+        return False
+    if x.requires_grad or any(p.requires_grad for p in module.parameters()):
+        return True
+    return state is not None and any(s.requires_grad for s in state)
+
+
+def _need_fp32_training(x: torch.Tensor, who: str) -> None:
+    if x.dtype != torch.float32:
+        raise NotImplementedError(f"{who}: the surrogate-gradient kernels are fp32; run {x.dtype} "
+                                  f"under torch.no_grad() or train in fp32")
+
+
+class GifLoopFunction(torch.autograd.Function):
+    """Differentiable GIF time loop: (h [rows,T,H], v0, theta0) -> (spikes, v_T, theta_T)."""
+
+    @staticmethod
+    def forward(ctx, h, v0, theta0, decay, L, alpha, threshold):
+        h = h.contiguous()
+        v = v0.detach().contiguous().clone()
+        theta = theta0.detach().contiguous().clone()
+        spikes, save_a, save_th = torch.empty_like(h), torch.empty_like(h), torch.empty_like(h)
+        ops.gif_train_forward(h, spikes, v, theta, save_a, save_th, float(decay), int(L), float(alpha),
+                              float(threshold))
+        ctx.save_for_backward(save_a, save_th)
+        ctx.cfg = (float(decay), int(L), float(alpha), float(threshold))
+        return spikes, v, theta
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_spikes, g_v, g_theta):
+        save_a, save_th = ctx.saved_tensors
+        g_h = torch.empty_like(save_a)
+        g_v = g_v.contiguous().clone()
+        g_theta = g_theta.contiguous().clone()
+        ops.gif_backward(save_a, save_th, g_spikes.contiguous(), g_h, g_v, g_theta, *ctx.cfg)
+        return g_h, g_v, g_theta, None, None, None, None
+
+
+def run_gif_loop_grad(h: torch.Tensor, state, *, decay: float, L: int, alpha: float, threshold: float):
+    """Autograd-recording twin of ``run_gif_loop`` (fp32, h [rows, T, H])."""
+    rows, _, H = h.shape
+    if state is None:
+        v = torch.zeros(rows, H, device=h.device, dtype=h.dtype)
+        theta = torch.full((rows, H), threshold, device=h.device, dtype=h.dtype)
+    else:
+        v, theta = state
+    spikes, v, theta = GifLoopFunction.apply(h, v, theta, decay, L, alpha, threshold)
+    return spikes, (v, theta)
 
 
 def run_gif_loop(h: torch.Tensor, state, *, decay: float, L: int, alpha: float, threshold: float,
@@ -90,6 +145,10 @@ class GIFNeuron(nn.Module):
 
     def forward(self, x: torch.Tensor, state=None) -> Tuple[torch.Tensor, Any]:
         _check_input(x, "GIFNeuron")
+        if wants_grad(self, x, state):
+            _need_fp32_training(x, "GIFNeuron")
+            return run_gif_loop_grad(self.currents(x), state, decay=self.decay, L=self.L,
+                                     alpha=self.alpha, threshold=self.threshold)
         with torch.no_grad():
             h = self.currents(x.detach())
             return run_gif_loop(h, state, decay=self.decay, L=self.L, alpha=self.alpha,

@@ -11,7 +11,10 @@ MI355X-first restructuring of ``SNNFFN.forward`` (reference ``snn_ffn.py:55-86``
   * both GIF time loops are single fused kernels with the state in registers;
   * the layer-2 kernel accumulates the spike mean in registers (``AURA_GIF_MEAN_OUT``), so the
     ``[B*S, T, D]`` spike tensor of layer 2 is never written to HBM.
-Forward only; dropout is applied as in the reference (identity in eval mode).
+Dropout is applied as in the reference (identity in eval mode).  When autograd is recording (fp32)
+the same restructuring holds -- layer-1 currents are still computed once per token and broadcast
+over T (``expand``; autograd sums the T gradients), the loops run through ``GifLoopFunction``
+(``aura_gif_train_forward`` / ``aura_gif_backward``) and the mean over T is a torch reduction.
 """
 from __future__ import annotations
 
@@ -20,7 +23,8 @@ from typing import Optional
 import torch
 import torch.nn as nn
 
-from .gif_neuron import GIFNeuron, _check_input, run_gif_loop
+from .gif_neuron import (GIFNeuron, _check_input, _need_fp32_training, run_gif_loop,
+                         run_gif_loop_grad, wants_grad)
 from .synapsis import Synapsis
 
 
@@ -44,6 +48,16 @@ class SNNFFN(nn.Module):
         T = self.num_timesteps
         rows = B * S
         n1, n2 = self.neuron1, self.neuron2
+        if wants_grad(self, x):
+            _need_fp32_training(x, "SNNFFN")
+            h1, _ = self.syn1(x.reshape(rows, 1, self.input_dim), state=None)
+            c1 = n1.currents(h1).expand(rows, T, self.hidden_dim)
+            spikes1, _ = run_gif_loop_grad(c1, None, decay=n1.decay, L=n1.L, alpha=n1.alpha,
+                                           threshold=n1.threshold)
+            h2, _ = self.syn2(spikes1, state=None)
+            spikes2, _ = run_gif_loop_grad(n2.currents(h2), None, decay=n2.decay, L=n2.L,
+                                           alpha=n2.alpha, threshold=n2.threshold)
+            return self.dropout(spikes2.mean(dim=1).reshape(B, S, self.output_dim))
         with torch.no_grad():
             # layer 1: currents are identical at every timestep -> one GEMM pair per token
             x1 = x.detach().reshape(rows, 1, self.input_dim)

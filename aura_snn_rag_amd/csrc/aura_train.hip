@@ -1,0 +1,334 @@
+// aura_train.hip -- surrogate-gradient training kernels and the prosody-modulated GIF loop
+// (SURVEY.md section 8f-4), fp32, channel-contiguous layout [rows][T][H].
+//
+//   GIF   forward (training): the loop of gif_neuron.py:54-69 that also saves, per step, the
+//         pre-clamp potential a_t and the threshold theta_{t-1} it was computed with;
+//   GIF   backward: BPTT through T steps with MultiBitSurrogate's triangular window
+//         (gif_neuron.py:16-22), the tensor-bound clamp (gradient reaches theta through the
+//         bounds when a value is clamped) and the threshold adaptation recurrence;
+//   LIF   one-step forward saving the surrogate input, and backward with
+//         LearnableSurrogateGradient (neuron.py:80-108): fast-sigmoid window + slope gradient;
+//   ProsodyModulatedGIF forward (prosody_gif.py:69-106): per-(row, t) attention gains scale the
+//         input, the effective threshold and the adaptation rate.
+// One lane owns VEC adjacent channels; state lives in registers over the whole T loop; HBM-bound.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/aura_hip.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+template <int VEC> struct V;
+template <> struct V<4> {
+    __device__ static void ld(const float* p, float (&x)[4]) { float4 t = *reinterpret_cast<const float4*>(p); x[0] = t.x; x[1] = t.y; x[2] = t.z; x[3] = t.w; }
+    __device__ static void st(float* p, const float (&x)[4]) { *reinterpret_cast<float4*>(p) = make_float4(x[0], x[1], x[2], x[3]); }
+};
+template <> struct V<1> {
+    __device__ static void ld(const float* p, float (&x)[1]) { x[0] = *p; }
+    __device__ static void st(float* p, const float (&x)[1]) { *p = x[0]; }
+};
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline int grid_for(int64_t items) {
+    int64_t b = (items + 255) / 256;
+    return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
+}
+inline int check_launch() { return hipGetLastError() == hipSuccess ? AURA_OK : AURA_E_LAUNCH; }
+
+struct GifP { float decay, Lf, alpha, thr0; };
+
+template <int VEC>
+__global__ __launch_bounds__(256) void gif_train_fwd_kernel(GifP p, const float* __restrict__ h,
+                                                            float* __restrict__ spikes, float* v_io,
+                                                            float* th_io, float* __restrict__ save_a,
+                                                            float* __restrict__ save_th, int64_t R,
+                                                            int64_t T, int64_t C) {
+    const int64_t cv = C / VEC, items = R * cv;
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < items;
+         it += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = it / cv, c0 = (it - row * cv) * VEC;
+        float v[VEC], th[VEC];
+        V<VEC>::ld(v_io + row * C + c0, v);
+        V<VEC>::ld(th_io + row * C + c0, th);
+        for (int64_t t = 0; t < T; ++t) {
+            const int64_t o = (row * T + t) * C + c0;
+            float x[VEC], a[VEC], s[VEC], thp[VEC];
+            V<VEC>::ld(h + o, x);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                thp[e] = th[e];
+                a[e] = v[e] * p.decay + x[e];
+                const float cl = p.Lf * th[e] * 2.0f;
+                const float b = fminf(fmaxf(a[e], -cl), cl);
+                const float n = b / (th[e] + 1e-6f);
+                s[e] = fminf(fmaxf(floorf(n), 0.0f), p.Lf);
+                v[e] = b - s[e] * th[e];
+                if (p.alpha > 0.0f) th[e] = th[e] + p.alpha * s[e] - p.alpha * (th[e] - p.thr0);
+            }
+            V<VEC>::st(spikes + o, s);
+            V<VEC>::st(save_a + o, a);
+            V<VEC>::st(save_th + o, thp);
+        }
+        V<VEC>::st(v_io + row * C + c0, v);
+        V<VEC>::st(th_io + row * C + c0, th);
+    }
+}
+
+// gv_io / gth_io: in = dL/dv_T, dL/dtheta_T; out = dL/dv_0, dL/dtheta_0
+template <int VEC>
+__global__ __launch_bounds__(256) void gif_bwd_kernel(GifP p, const float* __restrict__ save_a,
+                                                      const float* __restrict__ save_th,
+                                                      const float* __restrict__ g_spikes,
+                                                      float* __restrict__ g_h, float* gv_io,
+                                                      float* gth_io, int64_t R, int64_t T, int64_t C) {
+    const int64_t cv = C / VEC, items = R * cv;
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < items;
+         it += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = it / cv, c0 = (it - row * cv) * VEC;
+        float gv[VEC], gth[VEC];
+        V<VEC>::ld(gv_io + row * C + c0, gv);
+        V<VEC>::ld(gth_io + row * C + c0, gth);
+        for (int64_t t = T - 1; t >= 0; --t) {
+            const int64_t o = (row * T + t) * C + c0;
+            float a[VEC], thp[VEC], gs[VEC], gh[VEC];
+            V<VEC>::ld(save_a + o, a);
+            V<VEC>::ld(save_th + o, thp);
+            V<VEC>::ld(g_spikes + o, gs);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const float cl = p.Lf * thp[e] * 2.0f;
+                const float b = fminf(fmaxf(a[e], -cl), cl);
+                const float d = thp[e] + 1e-6f;
+                const float n = b / d;
+                const float s = fminf(fmaxf(floorf(n), 0.0f), p.Lf);
+                float gth_prev = gth[e];
+                float gs_tot = gs[e];
+                if (p.alpha > 0.0f) {            // theta_t = (thp + alpha*s) - alpha*(thp - thr0)
+                    gs_tot = gs_tot + p.alpha * gth[e];
+                    gth_prev = gth_prev - p.alpha * gth[e];
+                }
+                gs_tot = gs_tot - thp[e] * gv[e];   // v_t = b - s*thp
+                gth_prev = gth_prev - s * gv[e];
+                float gb = gv[e];
+                const float dist = fabsf(n - rintf(n));
+                const float tri = fminf(fmaxf(1.0f - 2.0f * dist, 0.0f), 1.0f);
+                const float sur = (n >= 0.0f && n <= p.Lf + 1.0f) ? tri : 0.0f;
+                const float gn = gs_tot * sur;
+                gb = gb + gn / d;
+                gth_prev = gth_prev + (-gn * b / (d * d));
+                float ga = 0.0f, gcl = 0.0f;
+                if (a[e] < -cl) gcl = -gb;
+                else if (a[e] > cl) gcl = gb;
+                else ga = gb;
+                gth_prev = gth_prev + gcl * (2.0f * p.Lf);
+                gh[e] = ga;
+                gv[e] = ga * p.decay;
+                gth[e] = gth_prev;
+            }
+            V<VEC>::st(g_h + o, gh);
+        }
+        V<VEC>::st(gv_io + row * C + c0, gv);
+        V<VEC>::st(gth_io + row * C + c0, gth);
+    }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void lif_train_fwd_kernel(const float* __restrict__ x,
+                                                            const float* __restrict__ mem_in,
+                                                            const float* __restrict__ beta,
+                                                            const float* __restrict__ thr,
+                                                            float* __restrict__ spk,
+                                                            float* __restrict__ mem_out,
+                                                            float* __restrict__ pre, int64_t B,
+                                                            int64_t C) {
+    const int64_t cv = C / VEC, items = B * cv;
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < items;
+         it += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = it / cv, c0 = (it - row * cv) * VEC;
+        float xv[VEC], m[VEC], bt[VEC], th[VEC], s[VEC], pr[VEC];
+        V<VEC>::ld(x + row * C + c0, xv);
+        V<VEC>::ld(mem_in + row * C + c0, m);
+        V<VEC>::ld(beta + c0, bt);
+        V<VEC>::ld(thr + c0, th);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const float mm = bt[e] * m[e] + xv[e];
+            pr[e] = mm - th[e];
+            s[e] = pr[e] > 0.0f ? 1.0f : 0.0f;
+            m[e] = mm - s[e] * th[e];
+        }
+        V<VEC>::st(spk + row * C + c0, s);
+        V<VEC>::st(mem_out + row * C + c0, m);
+        V<VEC>::st(pre + row * C + c0, pr);
+    }
+}
+
+// g_in = (g_mem_out + (g_spk - g_mem_out*thr) * slope/(|slope*pre|+1)^2); g_x = g_in;
+// g_mem_prev = beta * g_in; raw_slope = -(g_spk - g_mem_out*thr) * |pre|*sign(pre)/(slope*|pre|+1)^2
+template <int VEC>
+__global__ __launch_bounds__(256) void lif_bwd_kernel(const float* __restrict__ pre,
+                                                      const float* __restrict__ g_spk,
+                                                      const float* __restrict__ g_mem,
+                                                      const float* __restrict__ beta,
+                                                      const float* __restrict__ thr,
+                                                      const float* __restrict__ slope,
+                                                      float* __restrict__ g_x,
+                                                      float* __restrict__ g_mem_prev,
+                                                      float* __restrict__ raw_slope, int64_t B,
+                                                      int64_t C) {
+    const int64_t cv = C / VEC, items = B * cv;
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < items;
+         it += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = it / cv, c0 = (it - row * cv) * VEC;
+        float pr[VEC], gs[VEC], gm[VEC], bt[VEC], th[VEC], sl[VEC], gx[VEC], gp[VEC], rs[VEC];
+        V<VEC>::ld(pre + row * C + c0, pr);
+        V<VEC>::ld(g_spk + row * C + c0, gs);
+        V<VEC>::ld(g_mem + row * C + c0, gm);
+        V<VEC>::ld(beta + c0, bt);
+        V<VEC>::ld(thr + c0, th);
+        V<VEC>::ld(slope + c0, sl);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const float g_s = gs[e] - gm[e] * th[e];         // spk feeds the output and mem_out = mem - spk*thr
+            const float den = fabsf(sl[e] * pr[e]) + 1.0f;
+            const float g_pre = g_s * (sl[e] / (den * den));
+            const float g_m = gm[e] + g_pre;                 // grad of mem' = beta*mem + x
+            gx[e] = g_m;
+            gp[e] = bt[e] * g_m;
+            const float ap = fabsf(pr[e]);
+            const float sg = pr[e] > 0.0f ? 1.0f : (pr[e] < 0.0f ? -1.0f : 0.0f);
+            const float den2 = sl[e] * ap + 1.0f;
+            rs[e] = -g_s * ap * sg / (den2 * den2);
+        }
+        V<VEC>::st(g_x + row * C + c0, gx);
+        V<VEC>::st(g_mem_prev + row * C + c0, gp);
+        V<VEC>::st(raw_slope + row * C + c0, rs);
+    }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void gif_prosody_kernel(GifP p, float strength,
+                                                          const float* __restrict__ h,
+                                                          const float* __restrict__ gains,
+                                                          float* __restrict__ spikes, float* v_io,
+                                                          float* th_io, int64_t R, int64_t T, int64_t C) {
+    const int64_t cv = C / VEC, items = R * cv;
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < items;
+         it += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = it / cv, c0 = (it - row * cv) * VEC;
+        float v[VEC], th[VEC];
+        V<VEC>::ld(v_io + row * C + c0, v);
+        V<VEC>::ld(th_io + row * C + c0, th);
+        for (int64_t t = 0; t < T; ++t) {
+            const int64_t o = (row * T + t) * C + c0;
+            float x[VEC], s[VEC];
+            V<VEC>::ld(h + o, x);
+            const bool mod = gains != nullptr;
+            const float g = mod ? gains[row * T + t] : 1.0f;
+            const float scale = fminf(fmaxf(1.0f - strength * (g - 1.0f), 0.5f), 1.5f);
+            const float a_eff = mod ? p.alpha * g : p.alpha;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const float i_t = mod ? x[e] * g : x[e];
+                float vv = v[e] * p.decay + i_t;
+                const float te = mod ? th[e] * scale : th[e];
+                const float cl = p.Lf * te * 2.0f;
+                vv = fminf(fmaxf(vv, -cl), cl);
+                s[e] = fminf(fmaxf(floorf(vv / te), 0.0f), p.Lf);
+                v[e] = vv - s[e] * te;
+                if (p.alpha > 0.0f) th[e] = th[e] + a_eff * s[e] - a_eff * (th[e] - p.thr0);
+            }
+            V<VEC>::st(spikes + o, s);
+        }
+        V<VEC>::st(v_io + row * C + c0, v);
+        V<VEC>::st(th_io + row * C + c0, th);
+    }
+}
+
+}  // namespace
+
+#define AURA_VEC_DISPATCH(KERNEL, ITEMS4, ITEMS1, VECOK, ...)                                       \
+    do {                                                                                            \
+        if (VECOK) hipLaunchKernelGGL((KERNEL<4>), dim3(grid_for(ITEMS4)), dim3(256), 0, s, __VA_ARGS__); \
+        else hipLaunchKernelGGL((KERNEL<1>), dim3(grid_for(ITEMS1)), dim3(256), 0, s, __VA_ARGS__);  \
+    } while (0)
+
+extern "C" {
+
+int aura_gif_train_forward(const float* h, float* spikes, float* v, float* theta, float* save_a,
+                           float* save_theta, float decay, int L, float alpha, float threshold,
+                           int64_t rows, int64_t T, int64_t H, void* stream) {
+    if (rows < 0 || T < 0 || H < 0 || L < 0) return AURA_E_INVAL;
+    if (rows == 0 || H == 0) return AURA_OK;
+    if (!v || !theta || (T && (!h || !spikes || !save_a || !save_theta))) return AURA_E_INVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool vec = H % 4 == 0 && aligned16(h) && aligned16(spikes) && aligned16(v) && aligned16(theta) &&
+                     aligned16(save_a) && aligned16(save_theta);
+    const GifP p{decay, (float)L, alpha, threshold};
+    AURA_VEC_DISPATCH(gif_train_fwd_kernel, rows * (H / 4), rows * H, vec, p, h, spikes, v, theta, save_a,
+                      save_theta, rows, T, H);
+    return check_launch();
+}
+
+int aura_gif_backward(const float* save_a, const float* save_theta, const float* g_spikes, float* g_h,
+                      float* g_v, float* g_theta, float decay, int L, float alpha, float threshold,
+                      int64_t rows, int64_t T, int64_t H, void* stream) {
+    if (rows < 0 || T < 0 || H < 0 || L < 0) return AURA_E_INVAL;
+    if (rows == 0 || H == 0) return AURA_OK;
+    if (!g_v || !g_theta || (T && (!save_a || !save_theta || !g_spikes || !g_h))) return AURA_E_INVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool vec = H % 4 == 0 && aligned16(save_a) && aligned16(save_theta) && aligned16(g_spikes) &&
+                     aligned16(g_h) && aligned16(g_v) && aligned16(g_theta);
+    const GifP p{decay, (float)L, alpha, threshold};
+    AURA_VEC_DISPATCH(gif_bwd_kernel, rows * (H / 4), rows * H, vec, p, save_a, save_theta, g_spikes, g_h,
+                      g_v, g_theta, rows, T, H);
+    return check_launch();
+}
+
+int aura_lif_train_forward(const float* x, const float* mem_in, const float* beta,
+                           const float* threshold, float* spikes, float* mem_out, float* pre,
+                           int64_t B, int64_t size, void* stream) {
+    if (B < 0 || size < 0) return AURA_E_INVAL;
+    if (B == 0 || size == 0) return AURA_OK;
+    if (!x || !mem_in || !beta || !threshold || !spikes || !mem_out || !pre) return AURA_E_INVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool vec = size % 4 == 0 && aligned16(x) && aligned16(mem_in) && aligned16(beta) &&
+                     aligned16(threshold) && aligned16(spikes) && aligned16(mem_out) && aligned16(pre);
+    AURA_VEC_DISPATCH(lif_train_fwd_kernel, B * (size / 4), B * size, vec, x, mem_in, beta, threshold,
+                      spikes, mem_out, pre, B, size);
+    return check_launch();
+}
+
+int aura_lif_backward(const float* pre, const float* g_spikes, const float* g_mem, const float* beta,
+                      const float* threshold, const float* slope, float* g_x, float* g_mem_prev,
+                      float* raw_slope, int64_t B, int64_t size, void* stream) {
+    if (B < 0 || size < 0) return AURA_E_INVAL;
+    if (B == 0 || size == 0) return AURA_OK;
+    if (!pre || !g_spikes || !g_mem || !beta || !threshold || !slope || !g_x || !g_mem_prev || !raw_slope)
+        return AURA_E_INVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool vec = size % 4 == 0 && aligned16(pre) && aligned16(g_spikes) && aligned16(g_mem) &&
+                     aligned16(beta) && aligned16(threshold) && aligned16(slope) && aligned16(g_x) &&
+                     aligned16(g_mem_prev) && aligned16(raw_slope);
+    AURA_VEC_DISPATCH(lif_bwd_kernel, B * (size / 4), B * size, vec, pre, g_spikes, g_mem, beta, threshold,
+                      slope, g_x, g_mem_prev, raw_slope, B, size);
+    return check_launch();
+}
+
+int aura_gif_prosody_run(const float* h, const float* gains, float* spikes, float* v, float* theta,
+                         float decay, int L, float alpha, float threshold, float strength,
+                         int64_t rows, int64_t T, int64_t H, void* stream) {
+    if (rows < 0 || T < 0 || H < 0 || L < 0) return AURA_E_INVAL;
+    if (rows == 0 || H == 0) return AURA_OK;
+    if (!v || !theta || (T && (!h || !spikes))) return AURA_E_INVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool vec = H % 4 == 0 && aligned16(h) && aligned16(spikes) && aligned16(v) && aligned16(theta);
+    const GifP p{decay, (float)L, alpha, threshold};
+    AURA_VEC_DISPATCH(gif_prosody_kernel, rows * (H / 4), rows * H, vec, p, strength, h, gains, spikes, v,
+                      theta, rows, T, H);
+    return check_launch();
+}
+
+}  // extern "C"

@@ -134,6 +134,70 @@ def gif_run(h, out, v, theta, decay: float, L: int, alpha: float, threshold: flo
 
 
 # ---------------------------------------------------------------------------------------
+# surrogate-gradient training path + prosody-modulated GIF (fp32)
+# ---------------------------------------------------------------------------------------
+
+def _same_f32(shape, *named) -> None:
+    for t, n in named:
+        _need(t, n, torch.float32)
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError(f"{n}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+
+
+def gif_train_forward(h, spikes, v, theta, save_a, save_theta, decay: float, L: int, alpha: float,
+                      threshold: float) -> None:
+    """h [rows, T, H] -> spikes, save_a, save_theta [rows, T, H]; v, theta [rows, H] in/out."""
+    rows, T, H = h.shape
+    _same_f32((rows, T, H), (h, "h"), (spikes, "spikes"), (save_a, "save_a"), (save_theta, "save_theta"))
+    _same_f32((rows, H), (v, "v"), (theta, "theta"))
+    check(lib().aura_gif_train_forward(_p(h), _p(spikes), _p(v), _p(theta), _p(save_a), _p(save_theta),
+                                       decay, int(L), alpha, threshold, rows, T, H, _stream()),
+          "aura_gif_train_forward")
+
+
+def gif_backward(save_a, save_theta, g_spikes, g_h, g_v, g_theta, decay: float, L: int, alpha: float,
+                 threshold: float) -> None:
+    """g_v, g_theta [rows, H]: gradients of the final state in, of the initial state out."""
+    rows, T, H = save_a.shape
+    _same_f32((rows, T, H), (save_a, "save_a"), (save_theta, "save_theta"), (g_spikes, "g_spikes"),
+              (g_h, "g_h"))
+    _same_f32((rows, H), (g_v, "g_v"), (g_theta, "g_theta"))
+    check(lib().aura_gif_backward(_p(save_a), _p(save_theta), _p(g_spikes), _p(g_h), _p(g_v), _p(g_theta),
+                                  decay, int(L), alpha, threshold, rows, T, H, _stream()),
+          "aura_gif_backward")
+
+
+def lif_train_forward(x, mem_in, beta, threshold, spikes, mem_out, pre) -> None:
+    B, size = x.shape
+    _same_f32((B, size), (x, "x"), (mem_in, "mem_in"), (spikes, "spikes"), (mem_out, "mem_out"), (pre, "pre"))
+    _same_f32((size,), (beta, "beta"), (threshold, "threshold"))
+    check(lib().aura_lif_train_forward(_p(x), _p(mem_in), _p(beta), _p(threshold), _p(spikes), _p(mem_out),
+                                       _p(pre), B, size, _stream()), "aura_lif_train_forward")
+
+
+def lif_backward(pre, g_spikes, g_mem, beta, threshold, slope, g_x, g_mem_prev, raw_slope) -> None:
+    B, size = pre.shape
+    _same_f32((B, size), (pre, "pre"), (g_spikes, "g_spikes"), (g_mem, "g_mem"), (g_x, "g_x"),
+              (g_mem_prev, "g_mem_prev"), (raw_slope, "raw_slope"))
+    _same_f32((size,), (beta, "beta"), (threshold, "threshold"), (slope, "slope"))
+    check(lib().aura_lif_backward(_p(pre), _p(g_spikes), _p(g_mem), _p(beta), _p(threshold), _p(slope),
+                                  _p(g_x), _p(g_mem_prev), _p(raw_slope), B, size, _stream()),
+          "aura_lif_backward")
+
+
+def gif_prosody_run(h, gains, spikes, v, theta, decay: float, L: int, alpha: float, threshold: float,
+                    strength: float) -> None:
+    """h, spikes [rows, T, H]; gains [rows, T] or None; v, theta [rows, H] in/out."""
+    rows, T, H = h.shape
+    _same_f32((rows, T, H), (h, "h"), (spikes, "spikes"))
+    _same_f32((rows, H), (v, "v"), (theta, "theta"))
+    if gains is not None:
+        _same_f32((rows, T), (gains, "gains"))
+    check(lib().aura_gif_prosody_run(_p(h), _p(gains), _p(spikes), _p(v), _p(theta), decay, int(L), alpha,
+                                     threshold, strength, rows, T, H, _stream()), "aura_gif_prosody_run")
+
+
+# ---------------------------------------------------------------------------------------
 # episodic bank
 # ---------------------------------------------------------------------------------------
 

@@ -122,7 +122,10 @@ def secondary_neurons(dev):
     torch.manual_seed(0)
     ffn = SNNFFN(768, 3072, num_timesteps=16, L=8).to(dev).to(torch.bfloat16).eval()
     x = torch.randn(1, 512, 768, device=dev, dtype=torch.bfloat16)
-    ms = timed(lambda: ffn(x))
+    def ffn_forward():
+        with torch.no_grad():
+            return ffn(x)
+    ms = timed(ffn_forward)
     res["snnffn_config3_bf16"] = {"ms": ms, "neuron_timesteps_per_s": 512 * 16 * (3072 + 768) / (ms * 1e-3),
                                   "note": "module forward incl. 4 GEMMs; reference CPU path measured 315 ms (BASELINE.md)"}
     # one-shot write throughput (config 5 seeding path): rows of 768 fp32 into the bank

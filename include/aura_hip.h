@@ -192,6 +192,45 @@ int aura_bank_gather(const float* bank, const int32_t* idx, float* out, int64_t 
                      void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Surrogate-gradient training path and the prosody-modulated GIF (fp32, [rows][T][H] layout)
+ * ------------------------------------------------------------------------------------- */
+
+/* GIF loop for training: as aura_gif_run (fp32, no flags) and additionally saves, per step, the
+ * pre-clamp membrane potential (save_a) and the threshold the step started from (save_theta),
+ * both [rows][T][H].  Forward of GIFNeuron.forward when autograd is recording,
+ * src/core/language_zone/gif_neuron.py:54-69. */
+int aura_gif_train_forward(const float* h, float* spikes, float* v, float* theta, float* save_a,
+                           float* save_theta, float decay, int L, float alpha, float threshold,
+                           int64_t rows, int64_t T, int64_t H, void* stream);
+
+/* Backward of that loop (BPTT over T): g_spikes [rows][T][H] in; g_h [rows][T][H] out; g_v,
+ * g_theta [rows][H]: in = gradients of the final state, out = gradients of the initial state.
+ * Spike gradient = MultiBitSurrogate.backward (triangular window, gif_neuron.py:16-22); the
+ * clamp with tensor bounds routes the gradient of clamped values to theta, as autograd does. */
+int aura_gif_backward(const float* save_a, const float* save_theta, const float* g_spikes, float* g_h,
+                      float* g_v, float* g_theta, float decay, int L, float alpha, float threshold,
+                      int64_t rows, int64_t T, int64_t H, void* stream);
+
+/* LIF step for training: spikes, mem_out as aura_lif_run (T = 1) plus pre = beta*mem + x - thr
+ * (the surrogate's input), all [B][size]; mem_in is not modified. */
+int aura_lif_train_forward(const float* x, const float* mem_in, const float* beta,
+                           const float* threshold, float* spikes, float* mem_out, float* pre,
+                           int64_t B, int64_t size, void* stream);
+
+/* Backward of the LIF step with LearnableSurrogateGradient.backward (src/base/neuron.py:80-108):
+ * g_x, g_mem_prev [B][size] and raw_slope [B][size] (sum it over the batch to get d/d slope). */
+int aura_lif_backward(const float* pre, const float* g_spikes, const float* g_mem, const float* beta,
+                      const float* threshold, const float* slope, float* g_x, float* g_mem_prev,
+                      float* raw_slope, int64_t B, int64_t size, void* stream);
+
+/* ProsodyModulatedGIF.forward loop, src/core/language_zone/prosody_gif.py:69-106: gains [rows][T]
+ * (NULL = no modulation) scale the input, the effective threshold (x clamp(1 - strength*(g-1),
+ * 0.5, 1.5)) and the adaptation rate; no 1e-6 in the division (unlike GIFNeuron). */
+int aura_gif_prosody_run(const float* h, const float* gains, float* spikes, float* v, float* theta,
+                         float decay, int L, float alpha, float threshold, float strength,
+                         int64_t rows, int64_t T, int64_t H, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Brain-zone projection
  * ------------------------------------------------------------------------------------- */
 

@@ -435,3 +435,93 @@ def merge_topk(scores: torch.Tensor, idx: torch.Tensor, k: int) -> Tuple[torch.T
     i2 = torch.gather(idx, 1, order)
     order2 = torch.argsort(s2, dim=1, descending=True, stable=True)[:, :k]
     return torch.gather(s2, 1, order2), torch.gather(i2, 1, order2)
+
+
+# --------------------------------------------------------------------------------------
+# Differentiable restatements (surrogate gradients) and the prosody-modulated GIF
+# --------------------------------------------------------------------------------------
+
+
+class MultiBitSurrogateFn(torch.autograd.Function):
+    """floor/clamp forward, triangular surrogate backward: ``gif_neuron.py:6-22``."""
+
+    @staticmethod
+    def forward(ctx, inp, L):
+        ctx.save_for_backward(inp)
+        ctx.L = L
+        return torch.clamp(torch.floor(inp), 0, L)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        inp, = ctx.saved_tensors
+        dist = torch.abs(inp - torch.round(inp))
+        scale = torch.clamp(1.0 - 2.0 * dist, 0.0, 1.0)
+        in_range = (inp >= 0.0) & (inp <= ctx.L + 1.0)
+        return grad_output * in_range.float() * scale, None
+
+
+class LearnableSurrogateFn(torch.autograd.Function):
+    """Heaviside forward, fast-sigmoid backward incl. the slope gradient: ``neuron.py:70-108``."""
+
+    @staticmethod
+    def forward(ctx, inp, slope):
+        ctx.save_for_backward(inp, slope)
+        return (inp > 0).to(inp.dtype)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        inp, slope = ctx.saved_tensors
+        grad_input = grad_output * (slope / ((slope * inp).abs() + 1.0) ** 2)
+        raw = -grad_output * inp.abs() * inp.sign() / ((slope * inp.abs() + 1.0) ** 2)
+        extra = raw.ndim - slope.ndim
+        grad_slope = raw.sum(dim=list(range(extra))) if (slope.shape != raw.shape and extra > 0) else raw
+        return grad_input, grad_slope
+
+
+def gif_run_grad(h, v, theta, decay, L, alpha, threshold):
+    """``gif_run`` with autograd through the surrogate (fp32): the graph the reference builds in
+    ``gif_neuron.py:54-69`` when its inputs require grad."""
+    out = []
+    for t in range(h.shape[1]):
+        v = v * decay + h[:, t, :]
+        cl = L * theta * 2.0
+        v = torch.clamp(v, -cl, cl)
+        spike = MultiBitSurrogateFn.apply(v / (theta + 1e-6), L)
+        v = v - spike * theta
+        if alpha > 0:
+            theta = theta + alpha * spike - alpha * (theta - threshold)
+        out.append(spike)
+    return torch.stack(out, dim=1), v, theta
+
+
+def lif_step_grad(x, mem, beta, threshold, slope):
+    """``VectorizedLIFNeuron.forward`` with the learnable surrogate (``neuron.py:135-139``)."""
+    mem = beta * mem + x
+    spk = LearnableSurrogateFn.apply(mem - threshold, slope)
+    return spk, mem - spk * threshold
+
+
+def prosody_gif_run(h, v, theta, gains, decay, L, alpha, threshold, strength):
+    """``ProsodyModulatedGIF.forward`` loop (``prosody_gif.py:69-106``): attention gains [rows, T]
+    scale the input, the effective threshold (clamped to [0.5, 1.5] x) and the adaptation rate.
+    Note: no 1e-6 in the division, unlike ``GIFNeuron``."""
+    out = []
+    for t in range(h.shape[1]):
+        i_t = h[:, t, :]
+        if gains is not None:
+            g = gains[:, t].unsqueeze(1)
+            i_t = i_t * g
+        v = v * decay + i_t
+        th_eff = theta
+        if gains is not None:
+            scale = torch.clamp(1.0 - strength * (g - 1.0), 0.5, 1.5)
+            th_eff = theta * scale
+        cl = L * th_eff * 2.0
+        v = torch.clamp(v, -cl, cl)
+        spike = torch.clamp(torch.floor(v / th_eff), 0, L)
+        v = v - spike * th_eff
+        if alpha > 0:
+            a_eff = alpha * g if gains is not None else alpha
+            theta = theta + a_eff * spike - a_eff * (theta - threshold)
+        out.append(spike)
+    return torch.stack(out, dim=1), v, theta

@@ -127,6 +127,52 @@ def main():
     save("zone.pt", dict(x=xz, state={k: v.clone() for k, v in zone.state_dict().items()}, out=out,
                          avg_firing_rate=info["avg_firing_rate"]))
 
+    # --- surrogate-gradient training: GIF BPTT (upstream gradients through MultiBitSurrogate) -------------
+    torch.manual_seed(7)
+    g = G.GIFNeuron(20, 36, L=8, alpha=0.05)
+    x = (torch.randn(5, 12, 20) * 3).requires_grad_(True)
+    v0 = (0.3 * torch.randn(5, 36)).requires_grad_(True)
+    th0 = (1.0 + 0.2 * torch.rand(5, 36)).requires_grad_(True)
+    s, (v, th) = g(x, state=(v0, th0))
+    h = g.linear(x).detach()
+    ws, wv, wt = torch.randn_like(s), torch.randn_like(v), torch.randn_like(th)
+    loss = (s * ws).sum() + (v * wv).sum() + (th * wt).sum()
+    gx, gv0, gth0, gW, gb = torch.autograd.grad(loss, [x, v0, th0, g.linear.weight, g.linear.bias])
+    save("gif_grad.pt", dict(x=x.detach(), h=h, v0=v0.detach(), theta0=th0.detach(),
+                             weight=g.linear.weight.detach().clone(), bias=g.linear.bias.detach().clone(),
+                             decay=g.decay, L=8, alpha=0.05, threshold=g.threshold,
+                             spikes=s.detach(), v=v.detach(), theta=th.detach(), w_spikes=ws, w_v=wv, w_theta=wt,
+                             g_x=gx, g_v0=gv0, g_theta0=gth0, g_weight=gW, g_bias=gb))
+
+    # --- LIF with the learnable surrogate: 4 chained steps, gradients to inputs and slope ----------------
+    torch.manual_seed(8)
+    lif = N.VectorizedLIFNeuron(40, beta=0.9, threshold=0.5, init_slope=5.0)
+    xs = (0.6 * torch.randn(4, 3, 40)).requires_grad_(True)
+    outs = [lif(xs[t]) for t in range(4)]
+    wl = torch.randn(4, 2, 3, 40)
+    loss = sum((outs[t][0] * wl[t, 0]).sum() for t in range(4)) + (outs[3][1] * wl[3, 1]).sum()
+    gxs, gslope = torch.autograd.grad(loss, [xs, lif.slope])
+    save("lif_grad.pt", dict(x=xs.detach(), beta=0.9, threshold=0.5, slope=5.0, w=wl,
+                             spikes=torch.stack([o[0].detach() for o in outs]), mem=outs[3][1].detach(),
+                             g_x=gxs, g_slope=gslope))
+
+    # --- ProsodyModulatedGIF (forward) ---------------------------------------------------------------------
+    PG = L.load("src.core.language_zone.prosody_gif")
+    torch.manual_seed(9)
+    pg = PG.ProsodyModulatedGIF(24, 48, L=8, alpha=0.05, attention_modulation_strength=0.3)
+    x = torch.randn(4, 10, 24) * 3
+    gains = 0.5 + 2.5 * torch.rand(4, 10)
+    with torch.no_grad():
+        s1, (v1, t1) = pg(x, attention_gains=gains)
+        s2, (v2, t2) = pg(x, attention_gains=gains, state=(v1, t1))
+        s3, (v3, t3) = pg(x)
+        h = pg.linear(x)
+    save("prosody_gif.pt", dict(x=x, h=h, gains=gains, weight=pg.linear.weight.detach().clone(),
+                                bias=pg.linear.bias.detach().clone(), decay=pg.decay, L=8, alpha=0.05,
+                                threshold=pg.threshold, strength=0.3, spikes=s1, v=v1, theta=t1,
+                                spikes_cont=s2, v_cont=v2, theta_cont=t2, spikes_nogain=s3, v_nogain=v3,
+                                theta_nogain=t3))
+
 
 if __name__ == "__main__":
     main()

@@ -60,6 +60,48 @@ def test_oracle_snnffn_golden():
     assert torch.equal(O.hybridffn_forward(d["x"], d["hybrid_state"], T=d["T"], L=d["L"]), d["hybrid_out"])
 
 
+def _gif_grad_loss(d, s, v, th):
+    return (s * d["w_spikes"]).sum() + (v * d["w_v"]).sum() + (th * d["w_theta"]).sum()
+
+
+def test_oracle_training_golden():
+    """Surrogate-gradient BPTT of the oracle == the reference's autograd, bit for bit."""
+    d = load("gif_grad.pt")
+    x, v0, th0 = (d[k].clone().requires_grad_(True) for k in ("x", "v0", "theta0"))
+    W, b = d["weight"].clone().requires_grad_(True), d["bias"].clone().requires_grad_(True)
+    s, v, th = O.gif_run_grad(torch.nn.functional.linear(x, W, b), v0, th0, d["decay"], d["L"], d["alpha"],
+                              d["threshold"])
+    assert torch.equal(s, d["spikes"]) and torch.equal(v, d["v"]) and torch.equal(th, d["theta"])
+    grads = torch.autograd.grad(_gif_grad_loss(d, s, v, th), [x, v0, th0, W, b])
+    for g, k in zip(grads, ("g_x", "g_v0", "g_theta0", "g_weight", "g_bias")):
+        assert torch.equal(g, d[k]), k
+    d = load("lif_grad.pt")
+    xs = d["x"].clone().requires_grad_(True)
+    slope = torch.full((40,), d["slope"]).requires_grad_(True)
+    beta, thr = torch.full((40,), d["beta"]), torch.full((40,), d["threshold"])
+    mem, loss = torch.zeros(3, 40), 0.0
+    for t in range(4):
+        spk, mem = O.lif_step_grad(xs[t], mem, beta, thr, slope)
+        assert torch.equal(spk.detach(), d["spikes"][t])
+        loss = loss + (spk * d["w"][t, 0]).sum()
+    loss = loss + (mem * d["w"][3, 1]).sum()
+    gx, gs = torch.autograd.grad(loss, [xs, slope])
+    assert torch.equal(gx, d["g_x"]) and torch.equal(gs, d["g_slope"])
+
+
+def test_oracle_prosody_golden():
+    d = load("prosody_gif.pt")
+    H = d["weight"].shape[0]
+    args = (d["decay"], d["L"], d["alpha"], d["threshold"], d["strength"])
+    v0, t0 = torch.zeros(4, H), torch.full((4, H), d["threshold"])
+    s, v, th = O.prosody_gif_run(d["h"], v0, t0, d["gains"], *args)
+    assert torch.equal(s, d["spikes"]) and torch.equal(v, d["v"]) and torch.equal(th, d["theta"])
+    s, v, th = O.prosody_gif_run(d["h"], v, th, d["gains"], *args)
+    assert torch.equal(s, d["spikes_cont"]) and torch.equal(v, d["v_cont"]) and torch.equal(th, d["theta_cont"])
+    s, v, th = O.prosody_gif_run(d["h"], v0, t0, None, *args)
+    assert torch.equal(s, d["spikes_nogain"]) and torch.equal(v, d["v_nogain"]) and torch.equal(th, d["theta_nogain"])
+
+
 def _replay_bank(d, bank):
     torch.manual_seed(d["seed"])
     for i in range(d["feats"].shape[0]):
@@ -184,3 +226,64 @@ def test_hip_zone_golden(dev):
     out, info = zone.to(dev)(d["x"].to(dev))
     assert torch.allclose(out.cpu(), d["out"], rtol=1e-5, atol=1e-4)
     assert abs(info["avg_firing_rate"] - d["avg_firing_rate"]) < 1e-6
+
+
+def _close(a, b, tol=1e-5):
+    """north_star tolerance: |a - b| <= tol * max(1, |b|)."""
+    return bool(((a.cpu() - b).abs() <= tol * b.abs().clamp_min(1.0)).all())
+
+
+@pytest.mark.gpu
+def test_hip_training_golden(dev):
+    """HIP surrogate-gradient kernels vs the reference's autograd (gif_grad.pt / lif_grad.pt).  The
+    loop is fed the fixture's own currents so the comparison is the loop, not the GEMM."""
+    from aura_snn_rag_amd.base.neuron import VectorizedLIFNeuron
+    from aura_snn_rag_amd.core.language_zone.gif_neuron import run_gif_loop_grad
+    d = load("gif_grad.pt")
+    h = d["h"].to(dev).requires_grad_(True)
+    v0, th0 = d["v0"].to(dev).requires_grad_(True), d["theta0"].to(dev).requires_grad_(True)
+    s, (v, th) = run_gif_loop_grad(h, (v0, th0), decay=d["decay"], L=d["L"], alpha=d["alpha"],
+                                   threshold=d["threshold"])
+    assert torch.equal(s.cpu(), d["spikes"]) and torch.equal(v.cpu(), d["v"]) and torch.equal(th.cpu(), d["theta"])
+    loss = (s * d["w_spikes"].to(dev)).sum() + (v * d["w_v"].to(dev)).sum() + (th * d["w_theta"].to(dev)).sum()
+    gh, gv0, gth0 = torch.autograd.grad(loss, [h, v0, th0])
+    assert _close(gv0, d["g_v0"]) and _close(gth0, d["g_theta0"])
+    # dL/dx = dL/dh . W and dL/dW = dL/dh^T . x recover the reference's input / weight gradients
+    assert _close(gh.cpu() @ d["weight"], d["g_x"], 2e-5)
+    assert _close(torch.einsum("bth,bti->hi", gh.cpu(), d["x"]), d["g_weight"], 2e-5)
+    assert _close(gh.cpu().sum((0, 1)), d["g_bias"], 2e-5)
+
+    d = load("lif_grad.pt")
+    lif = VectorizedLIFNeuron(40, beta=d["beta"], threshold=d["threshold"], init_slope=d["slope"]).to(dev)
+    xs = d["x"].to(dev).requires_grad_(True)
+    loss = 0.0
+    for t in range(4):
+        spk, mem = lif(xs[t])
+        assert torch.equal(spk.detach().cpu(), d["spikes"][t])
+        loss = loss + (spk * d["w"][t, 0].to(dev)).sum()
+    assert torch.equal(mem.detach().cpu(), d["mem"])
+    loss = loss + (mem * d["w"][3, 1].to(dev)).sum()
+    gx, gs = torch.autograd.grad(loss, [xs, lif.slope])
+    assert _close(gx, d["g_x"]) and _close(gs, d["g_slope"])
+
+
+@pytest.mark.gpu
+def test_hip_prosody_golden(dev):
+    from aura_snn_rag_amd import ops
+    d = load("prosody_gif.pt")
+    H = d["weight"].shape[0]
+    h = d["h"].to(dev)
+    cfg = (d["decay"], d["L"], d["alpha"], d["threshold"], d["strength"])
+
+    def run(v, th, gains):
+        v, th, s = v.clone(), th.clone(), torch.empty_like(h)
+        ops.gif_prosody_run(h, gains, s, v, th, *cfg)
+        return s, v, th
+    v0, t0 = torch.zeros(4, H, device=dev), torch.full((4, H), d["threshold"], device=dev)
+    g = d["gains"].to(dev)
+    s, v, th = run(v0, t0, g)
+    assert torch.equal(s.cpu(), d["spikes"]) and torch.equal(v.cpu(), d["v"]) and torch.equal(th.cpu(), d["theta"])
+    s, v, th = run(v, th, g)
+    assert torch.equal(s.cpu(), d["spikes_cont"]) and torch.equal(v.cpu(), d["v_cont"]) and torch.equal(th.cpu(), d["theta_cont"])
+    s, v, th = run(v0, t0, None)
+    assert torch.equal(s.cpu(), d["spikes_nogain"]) and torch.equal(v.cpu(), d["v_nogain"]) and torch.equal(th.cpu(), d["theta_nogain"])

@@ -172,7 +172,8 @@ def test_snnffn_matches_oracle_pipeline(dev, dtype, T):
     ffn = SNNFFN(128, 512, num_timesteps=T, L=8).eval()
     x = torch.randn(2, 32, 128)
     ref = O.snnffn_forward(x.to(dtype), {k: v.to(dtype) for k, v in ffn.state_dict().items()}, T=T, L=8)
-    out = ffn.to(dev).to(dtype)(x.to(dev).to(dtype)).cpu()
+    with torch.no_grad():
+        out = ffn.to(dev).to(dtype)(x.to(dev).to(dtype)).cpu()
     assert out.shape == ref.shape and torch.isfinite(out.float()).all()
     diff = (out.float() - ref.float()).abs()
     frac = (diff > 1e-5).float().mean().item()

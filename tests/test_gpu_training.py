@@ -1,0 +1,187 @@
+"""GPU parity for SURVEY.md section 8f-4: surrogate-gradient backward kernels (GIF BPTT, LIF step)
+and the prosody-modulated GIF, against the CPU oracle's autograd restatement (itself bit-equal to
+the reference's autograd, tests/test_oracle_vs_reference.py).  Forward results are bit-exact;
+gradients within the north-star tolerance |a - b| <= 1e-5 * max(1, |b|)."""
+import math
+
+import pytest
+import torch
+
+from oracle import aura_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _close(a, b, tol=TOL):
+    a, b = a.detach().cpu(), b.detach()
+    bad = (a - b).abs() > tol * b.abs().clamp_min(1.0)
+    return not bool(bad.any())
+
+
+@pytest.mark.parametrize("rows,T,H,L,alpha", [(7, 12, 64, 8, 0.01), (3, 5, 37, 4, 0.05), (64, 16, 256, 8, 0.0),
+                                              (1, 1, 4, 16, 0.01), (33, 40, 100, 2, 0.2)])
+def test_gif_bptt_matches_oracle(dev, rows, T, H, L, alpha):
+    from aura_snn_rag_amd.core.language_zone.gif_neuron import run_gif_loop, run_gif_loop_grad
+    g = torch.Generator().manual_seed(rows * 131 + T * 7 + H)
+    decay, thr0 = math.exp(-0.1), 1.0
+    h = torch.randn(rows, T, H, generator=g) * 3
+    v0 = 0.4 * torch.randn(rows, H, generator=g)
+    t0 = 1.0 + 0.3 * torch.rand(rows, H, generator=g)
+    ws, wv, wt = (torch.randn(s, generator=g) for s in ((rows, T, H), (rows, H), (rows, H)))
+    # oracle
+    ho, vo, to = (x.clone().requires_grad_(True) for x in (h, v0, t0))
+    s, v, th = O.gif_run_grad(ho, vo, to, decay, L, alpha, thr0)
+    ref = torch.autograd.grad((s * ws).sum() + (v * wv).sum() + (th * wt).sum(), [ho, vo, to])
+    # HIP
+    hd, vd, td = (x.to(dev).requires_grad_(True) for x in (h, v0, t0))
+    sd, (vT, tT) = run_gif_loop_grad(hd, (vd, td), decay=decay, L=L, alpha=alpha, threshold=thr0)
+    assert torch.equal(sd.cpu(), s.detach()) and torch.equal(vT.cpu(), v.detach()) and torch.equal(tT.cpu(), th.detach())
+    got = torch.autograd.grad((sd * ws.to(dev)).sum() + (vT * wv.to(dev)).sum() + (tT * wt.to(dev)).sum(),
+                              [hd, vd, td])
+    for a, b, name in zip(got, ref, ("g_h", "g_v0", "g_theta0")):
+        assert _close(a, b), f"{name}: max err {(a.cpu() - b).abs().max().item():.3e}"
+    assert any(r.abs().sum() > 0 for r in ref)
+    # the training forward is the inference forward
+    with torch.no_grad():
+        s2, (v2, t2) = run_gif_loop(h.to(dev), (v0.to(dev), t0.to(dev)), decay=decay, L=L, alpha=alpha,
+                                    threshold=thr0, T=T)
+    assert torch.equal(s2, sd) and torch.equal(v2, vT) and torch.equal(t2, tT)
+
+
+def test_gif_clamp_routes_gradient_to_theta(dev):
+    """Values beyond +-2*L*theta are clamped: their gradient goes to theta through the tensor bounds
+    (torch.clamp semantics), not to the input."""
+    from aura_snn_rag_amd.core.language_zone.gif_neuron import run_gif_loop_grad
+    h = torch.tensor([[[100.0, -100.0, 1.5, 0.0]]])
+    ho = h.clone().requires_grad_(True)
+    to = torch.ones(1, 4, requires_grad=True)
+    s, v, th = O.gif_run_grad(ho, torch.zeros(1, 4), to, 1.0, 2, 0.0, 1.0)
+    ref = torch.autograd.grad(v.sum() + s.sum(), [ho, to])
+    hd = h.to(dev).requires_grad_(True)
+    td = torch.ones(1, 4, device=dev, requires_grad=True)
+    sd, (vd, _) = run_gif_loop_grad(hd, (torch.zeros(1, 4, device=dev), td), decay=1.0, L=2, alpha=0.0,
+                                    threshold=1.0)
+    got = torch.autograd.grad(vd.sum() + sd.sum(), [hd, td])
+    assert torch.equal(got[0].cpu(), ref[0]) and _close(got[1], ref[1])
+    assert ref[0][0, 0, 0] == 0 and ref[0][0, 0, 1] == 0           # clamped lanes: no input gradient
+
+
+def test_gif_module_training_step(dev):
+    """GIFNeuron / BalancedGIFNeuron record history when parameters require grad; weight gradients
+    flow through the library GEMM's autograd and match the oracle fed the same currents."""
+    from aura_snn_rag_amd.core.language_zone.gif_neuron import BalancedGIFNeuron, GIFNeuron
+    torch.manual_seed(0)
+    for cls in (GIFNeuron, BalancedGIFNeuron):
+        n = cls(32, 64, L=8, alpha=0.02).to(dev)
+        x = torch.randn(4, 10, 32, device=dev) * 3
+        w = torch.randn(4, 10, 64, device=dev)
+        cur = n.currents(x)
+        cur.retain_grad()
+        from aura_snn_rag_amd.core.language_zone.gif_neuron import run_gif_loop_grad
+        s, _ = run_gif_loop_grad(cur, None, decay=n.decay, L=n.L, alpha=n.alpha, threshold=n.threshold)
+        (s * w).sum().backward()
+        gh = cur.grad.clone()
+        grads_direct = [None if p.grad is None else p.grad.clone() for p in n.parameters()]
+        n.zero_grad()
+        s2, (v2, t2) = n(x)
+        assert s2.requires_grad and torch.equal(s2, s)
+        (s2 * w).sum().backward()
+        for p, gd in zip(n.parameters(), grads_direct):     # BalancedGIF's inherited `linear` is unused
+            assert (p.grad is None and gd is None) or torch.equal(p.grad, gd)
+        co = cur.detach().cpu().requires_grad_(True)
+        so, _, _ = O.gif_run_grad(co, torch.zeros(4, 64), torch.full((4, 64), float(n.threshold)), n.decay,
+                                  n.L, n.alpha, n.threshold)
+        (so * w.cpu()).sum().backward()
+        assert torch.equal(so.detach(), s.cpu()) and _close(gh, co.grad)
+        with torch.no_grad():
+            s3, _ = n(x)
+        assert not s3.requires_grad and torch.equal(s3, s)
+    with pytest.raises(NotImplementedError):
+        GIFNeuron(8, 8).to(dev).to(torch.bfloat16)(torch.randn(1, 2, 8, device=dev, dtype=torch.bfloat16))
+
+
+def test_snnffn_training_path(dev):
+    """Training-mode SNNFFN: same forward as the fused inference path, finite gradients everywhere,
+    and input gradients equal to the oracle's when it is fed the GPU's own GEMM outputs."""
+    from aura_snn_rag_amd.core.language_zone.snn_ffn import HybridFFN, SNNFFN
+    torch.manual_seed(1)
+    ffn = SNNFFN(64, 128, num_timesteps=4, L=8, dropout=0.0).to(dev)
+    x = torch.randn(2, 12, 64, device=dev, requires_grad=True)
+    y = ffn(x)
+    with torch.no_grad():
+        y0 = ffn(x)
+    assert y.requires_grad and torch.allclose(y, y0, atol=1e-6, rtol=0)
+    y.square().sum().backward()
+    assert torch.isfinite(x.grad).all() and x.grad.abs().sum() > 0
+    for name, p in ffn.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), name
+    assert ffn.syn1.weight.grad.abs().sum() > 0 and ffn.neuron2.linear.weight.grad.abs().sum() > 0
+    hy = HybridFFN(64, 128, num_timesteps=4, L=8, dropout=0.0).to(dev)
+    hy(x.detach()).sum().backward()
+    assert hy.gate.grad is not None and torch.isfinite(hy.gate.grad)
+
+
+@pytest.mark.parametrize("shape,size", [((5, 48), 48), ((2, 3, 33), 33), ((1, 4), 4), ((64, 1024), 1024)])
+def test_lif_surrogate_gradients(dev, shape, size):
+    from aura_snn_rag_amd.base.neuron import VectorizedLIFNeuron
+    g = torch.Generator().manual_seed(size)
+    lif = VectorizedLIFNeuron(size, beta=0.9, threshold=0.6, init_slope=4.0).to(dev)
+    with torch.no_grad():
+        lif.slope.copy_((2 + 6 * torch.rand(size, generator=g)).to(dev))
+    xs = [torch.randn(shape, generator=g) for _ in range(3)]
+    ws = [torch.randn(shape, generator=g) for _ in range(4)]
+    xo = [x.clone().requires_grad_(True) for x in xs]
+    slope = lif.slope.detach().cpu().clone().requires_grad_(True)
+    beta, thr = lif.beta.cpu(), lif.threshold.cpu()
+    mem, loss = torch.zeros(shape), 0.0
+    spikes_ref = []
+    for t in range(3):
+        spk, mem = O.lif_step_grad(xo[t], mem, beta, thr, slope)
+        spikes_ref.append(spk.detach())
+        loss = loss + (spk * ws[t]).sum()
+    loss = loss + (mem * ws[3]).sum()
+    ref = torch.autograd.grad(loss, xo + [slope])
+    xd = [x.to(dev).requires_grad_(True) for x in xs]
+    loss = 0.0
+    for t in range(3):
+        spk, m = lif(xd[t])
+        assert torch.equal(spk.detach().cpu(), spikes_ref[t])
+        loss = loss + (spk * ws[t].to(dev)).sum()
+    assert torch.equal(m.detach().cpu(), mem.detach())
+    loss = loss + (m * ws[3].to(dev)).sum()
+    got = torch.autograd.grad(loss, xd + [lif.slope])
+    for a, b in zip(got[:3], ref[:3]):
+        assert _close(a, b)
+    # slope gradient is a sum over the batch: tolerance relative to the summed magnitude
+    assert torch.allclose(got[3].cpu(), ref[3], rtol=1e-4, atol=1e-5 * max(1.0, ref[3].abs().max().item()))
+    # reset + no-grad call go back to the in-place inference kernel
+    lif.reset_mem()
+    with torch.no_grad():
+        s0, m0 = lif(xs[0].to(dev))
+    assert not s0.requires_grad and torch.equal(s0.cpu(), spikes_ref[0])
+
+
+@pytest.mark.parametrize("B,T,I,H", [(4, 10, 24, 48), (3, 7, 9, 21), (16, 32, 64, 256)])
+def test_prosody_gif_module(dev, B, T, I, H):
+    from aura_snn_rag_amd.core.language_zone.prosody_gif import ProsodyModulatedGIF
+    torch.manual_seed(B + T)
+    pg = ProsodyModulatedGIF(I, H, L=8, alpha=0.05, attention_modulation_strength=0.3).to(dev)
+    x = torch.randn(B, T, I, device=dev) * 3
+    gains = (0.2 + 3.0 * torch.rand(B, T)).to(dev)
+    with torch.no_grad():
+        h = pg.linear(x).cpu()
+        for gn in (gains, None):
+            s, (v, th) = pg(x, attention_gains=gn)
+            rs, rv, rt = O.prosody_gif_run(h, torch.zeros(B, H), torch.full((B, H), pg.threshold),
+                                           None if gn is None else gn.cpu(), pg.decay, 8, 0.05, pg.threshold, 0.3)
+            assert torch.equal(s.cpu(), rs) and torch.equal(v.cpu(), rv) and torch.equal(th.cpu(), rt)
+            s2, (v2, t2) = pg(x, attention_gains=gn, state=(v, th))
+            rs2, rv2, rt2 = O.prosody_gif_run(h, rv, rt, None if gn is None else gn.cpu(), pg.decay, 8, 0.05,
+                                              pg.threshold, 0.3)
+            assert torch.equal(s2.cpu(), rs2) and torch.equal(v2.cpu(), rv2) and torch.equal(t2.cpu(), rt2)
+    with pytest.raises(NotImplementedError):
+        pg(x)                                            # parameters require grad, grad mode on
+    with pytest.raises(ValueError):
+        with torch.no_grad():
+            pg(x, attention_gains=gains[:, :-1])

@@ -140,3 +140,42 @@ def test_product_modules_construct_like_the_reference():
     g = GIFNeuron(6, 10, L=8)
     r = R["gif"].GIFNeuron(6, 10, L=8)
     assert (g.decay, g.threshold, g.alpha, g.L) == (r.decay, r.threshold, r.alpha, r.L)
+
+
+def test_surrogate_gradients_and_prosody_bit_exact():
+    """Differentiable restatements (section 8f-4) == the reference's autograd graph."""
+    G = L.load("src.core.language_zone.gif_neuron")
+    N = L.load("base.neuron")
+    PG = L.load("src.core.language_zone.prosody_gif")
+    torch.manual_seed(11)
+    for alpha in (0.0, 0.05):
+        g = G.GIFNeuron(12, 28, L=4, alpha=alpha)
+        x = (torch.randn(3, 9, 12) * 4).requires_grad_(True)
+        v0 = (0.5 * torch.randn(3, 28)).requires_grad_(True)
+        t0 = (1 + 0.3 * torch.rand(3, 28)).requires_grad_(True)
+        ws = torch.randn(3, 9, 28)
+        rs, (rv, rt) = g(x, state=(v0, t0))
+        ref = torch.autograd.grad((rs * ws).sum() + rv.sum() - rt.sum(), [x, v0, t0, g.linear.weight])
+        os_, ov, ot = O.gif_run_grad(g.linear(x), v0, t0, g.decay, 4, alpha, g.threshold)
+        mine = torch.autograd.grad((os_ * ws).sum() + ov.sum() - ot.sum(), [x, v0, t0, g.linear.weight])
+        assert torch.equal(rs, os_) and all(torch.equal(a, b) for a, b in zip(ref, mine))
+    lif = N.VectorizedLIFNeuron(10, 0.9, 0.6, init_slope=3.0)
+    x = torch.randn(2, 4, 10).requires_grad_(True)
+    w = torch.randn(2, 4, 10)
+    s1, m1 = lif(x)
+    s2, m2 = lif(x * 0.5)
+    ref = torch.autograd.grad(((s1 + s2) * w).sum() + m2.sum(), [x, lif.slope])
+    slope = lif.slope.detach().clone().requires_grad_(True)
+    a1, b1 = O.lif_step_grad(x, torch.zeros_like(x), lif.beta, lif.threshold, slope)
+    a2, b2 = O.lif_step_grad(x * 0.5, b1, lif.beta, lif.threshold, slope)
+    mine = torch.autograd.grad(((a1 + a2) * w).sum() + b2.sum(), [x, slope])
+    assert all(torch.equal(a, b) for a, b in zip(ref, mine))
+    pg = PG.ProsodyModulatedGIF(8, 20, L=8, alpha=0.02, attention_modulation_strength=0.4)
+    x = torch.randn(3, 7, 8) * 3
+    gains = 0.5 + 2.5 * torch.rand(3, 7)
+    with torch.no_grad():
+        for gn in (gains, None):
+            rs, (rv, rt) = pg(x, attention_gains=gn)
+            os_, ov, ot = O.prosody_gif_run(pg.linear(x), torch.zeros(3, 20), torch.full((3, 20), pg.threshold),
+                                            gn, pg.decay, 8, 0.02, pg.threshold, 0.4)
+            assert torch.equal(rs, os_) and torch.equal(rv, ov) and torch.equal(rt, ot)
