@@ -22,6 +22,7 @@ ERRORS = {-1: "AURA_E_INVAL (bad argument)", -2: "AURA_E_LAUNCH (HIP launch erro
 DTYPE_F32, DTYPE_BF16 = 0, 1
 GIF_TIME_INVARIANT, GIF_MEAN_OUT = 1, 2
 KNN_FORCE_DENSE = 1
+KNN_FP32_SCAN = 2
 
 # name -> (restype, argtypes); mirrors include/aura_hip.h one to one
 P, I64, I32, F, I = c_void_p, c_int64, c_int32, c_float, c_int
@@ -55,6 +56,7 @@ SIGNATURES = {
     "aura_profile_begin": (I, [I]),
     "aura_profile_end": (I, [P, I]),
     "aura_profile_last_scan": (I, [P, P]),
+    "aura_profile_last_scan_kind": (I, []),
 }
 
 

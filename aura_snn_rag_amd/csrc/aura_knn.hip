@@ -1465,6 +1465,8 @@ struct Workspace {
     int32_t* cand2_idx;
     float* dense;        // [qb][dense cols]
     float* gmax;         // [qb][THR_MAX_GROUPS]
+    uint16_t* qhat;      // [qb rounded up to 256][768] bf16 query fragments (two-stage path)
+    float4* rowc;        // [N] per-row score constants (two-stage path)
     int cap, cap2;
     int qp;              // queries per pass
     int64_t bytes;
@@ -1505,6 +1507,8 @@ inline Workspace carve(void* base, int64_t N, int64_t nq, int k) {
     w.cand2_idx = reinterpret_cast<int32_t*>(take((int64_t)qb * w.cap2 * 4));
     w.dense = reinterpret_cast<float*>(take((int64_t)qb * cols * 4));
     w.gmax = reinterpret_cast<float*>(take((int64_t)qb * THR_MAX_GROUPS * 4));
+    w.qhat = reinterpret_cast<uint16_t*>(take(((int64_t)qb + 255) / 256 * 256 * 768 * 2));
+    w.rowc = reinterpret_cast<float4*>(take((N > 0 ? N : 1) * 16));
     w.bytes = off;
     return w;
 }
@@ -1533,6 +1537,7 @@ struct ProfileState {
     int cap = 0, used = 0;
     bool on = false;
     int64_t rows = 0, nq = 0;   // rows x queries scored by the last profiled main-scan launch
+    int kind = 0;               // 0 = fp32 MFMA scan, 1 = bf16 prefilter scan
 };
 ProfileState g_prof;
 
@@ -1610,6 +1615,97 @@ inline int dispatch_scan(const ScanArgs& a, int mode, int64_t ntiles_grid, hipSt
     return launch_scan<8, 1, 4>(a, mode, ntiles_grid, s);                   // 256 q x 128 rows
 }
 
+#include "aura_knn_coarse.inl"
+
+// Two-stage recall of one query pass (see aura_knn_coarse.inl).  Returns AURA_OK after queuing
+// sample scan -> threshold -> filter scan -> refine; the caller skips the fp32 pipeline.
+inline int run_coarse_pass(const float* bank, const float* inv_norm, const float* meta,
+                           const float* qptr, float now, int64_t N, int64_t D, int nqb, int k,
+                           int32_t idx_base, float* out_scores, int32_t* out_idx,
+                           const Workspace& w, int32_t* overflow_out, bool reset_flag, hipStream_t s) {
+    int rc;
+    // sample: strided 128-row logical tiles (8 coarse tiles each), sized as for the fp32 path
+    int64_t sample_rows = (int64_t)k * N / 512;
+    if (sample_rows < 8192) sample_rows = 8192;
+    if (sample_rows < (int64_t)k * 48) sample_rows = (int64_t)k * 48;
+    const int64_t ntiles128 = N / 128;                       // whole logical tiles only
+    int64_t n_sample = (sample_rows + 127) / 128;
+    if (n_sample * 8 > THR_MAX_GROUPS) n_sample = THR_MAX_GROUPS / 8;
+    if (n_sample > ntiles128) n_sample = ntiles128;
+    const int tile_step = (int)(ntiles128 / n_sample);
+    const int G = (int)n_sample * 8;
+    if (G < k) return AURA_E_INVAL;                          // ruled out by coarse_eligible()
+
+    // per-call preparation: bf16 query fragments + 1/||q|| (+ overflow-flag reset), row constants
+    const int KS = D <= 256 ? 8 : (D <= 512 ? 16 : 24);
+    const int64_t nq_pad = ((int64_t)nqb + 255) / 256 * 256;
+    const float e_cos = 0.00390625f * (1.0f + 0.001953125f) + 2.0f * (float)D * 5.9604645e-8f + 1e-5f;
+    const int qblocks = (int)(nq_pad / 4);
+    hipLaunchKernelGGL(coarse_prep_kernel, dim3((unsigned)(qblocks + (N + 255) / 256)), dim3(256), 0, s,
+                       qptr, (int64_t)nqb, nq_pad, D, KS, w.qhat, w.inv_q,
+                       reset_flag ? overflow_out : nullptr, qblocks, meta, inv_norm, N, now, e_cos,
+                       w.rowc);
+    if ((rc = check_launch())) return rc;
+    CoarseArgs c{};
+    c.bank = bank; c.rowc = w.rowc; c.qhat = w.qhat; c.inv_q = w.inv_q;
+    static const int cs_dbg = getenv("AURA_CS_DBG") ? atoi(getenv("AURA_CS_DBG")) : 0;
+    c.dbg = cs_dbg;
+    c.N = N; c.D = D; c.nq = nqb;
+    c.thr = w.thr; c.cnt = w.cnt; c.cand_scores = w.cand_scores; c.cand_idx = w.cand_idx;
+    c.cap = w.cap;
+    const int cus = device_cu_count();
+
+    c.n_tiles = G; c.tile_step = tile_step; c.n_sample = (int)n_sample;
+    c.gmax = w.gmax; c.gmax_ld = THR_MAX_GROUPS;
+    {
+        const int64_t items = (int64_t)G * ((nqb + 255) / 256);
+        if ((rc = dispatch_coarse(c, CS_MODE_SAMPLE, (int)(items < cus ? items : cus), s))) return rc;
+    }
+    {
+        const dim3 tg((unsigned)((nqb + 3) / 4)), tb(256);
+#define AURA_THR(PER)                                                                              \
+    hipLaunchKernelGGL((coarse_threshold_kernel<PER>), tg, tb, 0, s, w.gmax, (int64_t)THR_MAX_GROUPS, \
+                       G, k, nqb, w.thr, w.cnt)
+        if (G <= 512) AURA_THR(8);
+        else if (G <= 1024) AURA_THR(16);
+        else if (G <= 2048) AURA_THR(32);
+        else AURA_THR(64);
+#undef AURA_THR
+    }
+    if ((rc = check_launch())) return rc;
+
+    c.n_tiles = (N + CS_ROWS - 1) / CS_ROWS; c.gmax = nullptr;
+    const bool prof = g_prof.on && g_prof.used < g_prof.cap;
+    if (prof) {
+        (void)hipEventRecord(g_prof.start[g_prof.used], s);
+        g_prof.rows = N; g_prof.nq = nqb; g_prof.kind = 1;
+    }
+    {
+        const int64_t items = c.n_tiles * ((nqb + 255) / 256);
+        if ((rc = dispatch_coarse(c, CS_MODE_FILTER, (int)(items < cus ? items : cus), s))) return rc;
+    }
+    if (prof) (void)hipEventRecord(g_prof.stop[g_prof.used++], s);
+
+    RefineArgs r{};
+    r.bank = bank; r.inv_norm = inv_norm; r.meta = meta; r.queries = qptr; r.inv_q = w.inv_q;
+    r.now = now; r.e_cos = e_cos; r.N = N; r.D = D; r.k = k; r.cnt = w.cnt;
+    r.cand_scores = w.cand_scores; r.cand_idx = w.cand_idx; r.cap = w.cap; r.idx_base = idx_base;
+    r.out_scores = out_scores; r.out_idx = out_idx; r.overflow = overflow_out;
+    const int64_t Dpad = (D + 31) / 32 * 32;
+    size_t lds = (size_t)8 * RF_ROWS * (RF_KC + 4) * 4 + (size_t)Dpad * 4;
+    if (lds < (size_t)RF_CAP * 12) lds = (size_t)RF_CAP * 12;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(coarse_refine_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                8 * RF_ROWS * (RF_KC + 4) * 4 + 768 * 4) != hipSuccess)
+            return AURA_E_LAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(coarse_refine_kernel, dim3((unsigned)nqb), dim3(RF_THREADS), lds, s, r);
+    return check_launch();
+}
+
 }  // namespace
 
 extern "C" {
@@ -1676,7 +1772,7 @@ int aura_knn_search_ex(const float* bank, const float* inv_norm, const float* me
                        int32_t* overflow_out, const float* centroids, int nprobe, void* stream) {
     if (N < 0 || D <= 0 || nq < 0 || k <= 0 || k > SEL_MAX_K || k > N) return AURA_E_INVAL;
     if (centroids && (nprobe <= 0 || nprobe > 256)) return AURA_E_INVAL;
-    if (flags & ~AURA_KNN_FORCE_DENSE) return AURA_E_INVAL;
+    if (flags & ~(AURA_KNN_FORCE_DENSE | AURA_KNN_FP32_SCAN)) return AURA_E_INVAL;
     if (nq == 0) return AURA_OK;
     if (!bank || !inv_norm || !meta || !queries || !out_scores || !out_idx || !workspace)
         return AURA_E_INVAL;
@@ -1695,9 +1791,19 @@ int aura_knn_search_ex(const float* bank, const float* inv_norm, const float* me
         const int br = tile_rows_for(nqb);
         const int64_t ntiles = (N + br - 1) / br;
 
-        hipLaunchKernelGGL(query_prep_kernel, dim3((unsigned)((nqb + 3) / 4)), dim3(256), 0, s,
-                           qptr, w.inv_q, (int64_t)nqb, D, qb0 == 0 ? overflow_out : nullptr);
-        if ((rc = check_launch())) return rc;
+        if (!coarse_eligible(bank, qptr, q_loc, centroids, N, D, k, flags)) {
+            hipLaunchKernelGGL(query_prep_kernel, dim3((unsigned)((nqb + 3) / 4)), dim3(256), 0, s,
+                               qptr, w.inv_q, (int64_t)nqb, D, qb0 == 0 ? overflow_out : nullptr);
+            if ((rc = check_launch())) return rc;
+        }
+
+        if (coarse_eligible(bank, qptr, q_loc, centroids, N, D, k, flags)) {
+            if ((rc = run_coarse_pass(bank, inv_norm, meta, qptr, now, N, D, nqb, k, idx_base,
+                                      out_scores + qb0 * k, out_idx + qb0 * k, w, overflow_out,
+                                      qb0 == 0, s)))
+                return rc;
+            continue;
+        }
 
         ScanArgs a{};
         a.bank = bank; a.inv_norm = inv_norm; a.meta = meta; a.loc = loc;
@@ -1782,6 +1888,7 @@ int aura_knn_search_ex(const float* bank, const float* inv_norm, const float* me
                 (void)hipEventRecord(g_prof.start[g_prof.used], s);
                 g_prof.rows = N - n_sample_tiles * br;
                 g_prof.nq = nqb;   // all query blocks of the pass are scored by this one launch
+                g_prof.kind = 0;
             }
             static const bool force_v1 = getenv("AURA_SCAN_V1") != nullptr;
             if (nqb > 128 && !force_v1) {
@@ -2058,6 +2165,8 @@ int aura_profile_end(float* ms_out_host, int max_out) {
     }
     return n;
 }
+
+int aura_profile_last_scan_kind(void) { return g_prof.kind; }
 
 int aura_profile_last_scan(int64_t* rows_out, int64_t* nq_out) {
     if (!rows_out || !nq_out) return AURA_E_INVAL;

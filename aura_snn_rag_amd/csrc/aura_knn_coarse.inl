@@ -1,0 +1,652 @@
+// aura_knn_coarse.inl -- two-stage exact recall: bf16 matrix-core prefilter + fp32 re-scoring.
+// Included by aura_knn.hip (same translation unit: shares ord_key, CNT_STRIDE, the workspace).
+//
+// Why: the fp32 matrix pipe (v_mfma_f32_32x32x2_f32, 1/16 of the bf16 rate) bounds the exact scan
+// at ~0.35 ms for 256 queries x 100 k rows.  A scan in bf16 is bound by reading the bank once from
+// HBM instead.  Results stay those of the fp32 path because the bf16 score is only used as a
+// bound:
+//     |cos_bf16 - cos_fp32| <= E_cos  with  E_cos = 2^-8 (1 + 2^-9) + 2 D 2^-24 + 1e-5
+// (round-to-nearest bf16 of both operands, Cauchy-Schwarz on the normalised vectors, fp32
+// accumulation of D terms in either pipe), so with  E_row = 0.5 E_cos |strength_row|
+//     L = coarse - E_row  <=  exact score  <=  coarse + E_row = U.
+//   1. coarse_scan<SAMPLE>: group maxima of L over a strided sample of 16-row groups;
+//      sample_threshold_kernel: T = k-th largest group maximum  (k distinct rows score >= T);
+//   2. coarse_scan<FILTER> over every row: rows with U >= T go to the query's candidate list;
+//   3. coarse_refine_kernel, one workgroup per query: T2 = k-th largest L of the candidates
+//      (>= T, still a lower bound of the k-th best exact score); survivors U >= T2 are re-scored
+//      with the fp32 path's own arithmetic (same fmaf order as the MFMA chain, same epilogue) and
+//      the top k of those exact scores are returned, ties to the lower row -- bit-identical to
+//      the fp32 scan whenever the candidate lists fit (else the overflow flag sends the caller
+//      to the fp32 path).
+//
+// coarse_scan design (one 512-thread workgroup per CU, persistent over a contiguous span of
+// 16-row tiles):
+//   * queries are STATIONARY: wave w keeps its 32 queries as bf16 MFMA B-fragments in registers
+//     for the whole launch (2 x KS x 4 VGPRs, KS = ceil(D/32) <= 24) -- no query traffic at all;
+//   * bank rows stream HBM -> LDS as fp32 by global_load_lds (16 B per lane, full 128-B lines,
+//     no VGPR staging) into a 3-slot ring: two tiles (2 x 48 KB) are in flight per CU while a
+//     third is consumed; one s_barrier per tile, counted s_waitcnt vmcnt so the prefetch spans it;
+//   * every wave reads the whole tile from LDS (conflict-free XOR-swizzled image, swizzle applied
+//     on the global address), converts to bf16 in registers and issues 2 KS
+//     v_mfma_f32_16x16x32_bf16 per tile;
+//   * the steady-state loop has no ordinary global load and no returning atomic (hipcc would wait
+//     vmcnt(0) for those and drain the prefetch): per-row constants arrive through the same
+//     global_load_lds ring and candidates are buffered in LDS and flushed per span.
+// Traffic: the bank once (N D 4 bytes) + 20 B of row constants per row.
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef float f32x8v __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
+
+constexpr int CS_THREADS = 256;           // 4 waves (one per SIMD, 512 registers each), 64 queries per wave
+constexpr int CS_QB = 4;                 // 16-query MFMA column blocks per wave
+constexpr int CS_ROWS = 16;              // bank rows per tile
+constexpr int CS_SLOTS = 3;
+constexpr int CS_AUX_BYTES = 1024;       // per slot: row constants (64 lanes x 16 B, first 16 used)
+constexpr int CS_BUF = 832;              // candidate entries buffered per workgroup
+constexpr int CS_MODE_SAMPLE = 0, CS_MODE_FILTER = 1;
+constexpr int64_t COARSE_MIN_ROWS = 16384;
+constexpr int COARSE_MAX_K = 256;
+constexpr int RF_THREADS = 512;
+constexpr int RF_CAP = 4096;             // candidates per query the refine kernel holds in LDS
+constexpr int RF_SURV = 1024;            // survivors re-scored per query at most
+constexpr int RF_KC = 256;               // k-chunk of the re-scoring stage
+constexpr int RF_ROWS = 16;              // survivors per wave and round
+
+struct CoarseArgs {
+    const float* bank;
+    const float4* rowc;      // [N] per-row score constants {A, B_up, B_lo, -} (coarse_prep_kernel)
+    const uint16_t* qhat;    // bf16 query fragments, [nq/256][4 waves][4 blocks][KS][64 lanes][8]
+    const float* inv_q;      // [nq]
+    int64_t N, D;
+    int nq;
+    int64_t n_tiles;         // 16-row tiles this launch walks (per 256-query block)
+    int tile_step, n_sample; // SAMPLE: tile j -> logical 128-row tile (j/8)*tile_step, sub-tile j%8
+    float* gmax;             // SAMPLE out: [nq][gmax_ld], group = tile j
+    int64_t gmax_ld;
+    const uint32_t* thr;     // FILTER in: [nq] ordered keys
+    int32_t* cnt;            // [nq][CNT_STRIDE]
+    float* cand_scores;      // [nq][cap]: U
+    int32_t* cand_idx;
+    int cap;
+    int dbg;                 // AURA_CS_DBG timing ablations (results invalid when non-zero)
+};
+
+__device__ __forceinline__ void glds16(const float* g, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ void glds4(const float* g, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
+}
+
+// MFMA with the stationary (query) operand in an accumulation register: 4 waves per workgroup own
+// 512 registers each, but hipcc only places MFMA B operands in the 256 architectural VGPRs, so
+// the 384 registers of query fragments are pinned by hand: the first CS_QA fragments live in
+// AGPRs (the hardware reads srcB from either file), the rest in VGPRs.  Hazards the compiler
+// would cover for its own MFMAs are covered by the s_nop statements around the groups.
+constexpr int CS_QA = 58;   // fragments (4 registers each) kept in AGPRs, next to the 16 accumulators
+template <bool QA, bool LAST>
+__device__ __forceinline__ void mfma_bf16_q(f32x4v& acc, const bf16x8v& af, const bf16x8v& q) {
+    // s_nop 1 in front: two wait states between a VALU write of an operand register (the bf16
+    // convert, or a register the compiler reloaded just before this statement) and the MFMA reading
+    // it; they elapse while the previous MFMA still occupies the pipe.
+    // LAST (the tile's final k-step): 12 wait states behind the MFMA, INSIDE the statement, because
+    // the compiler may read or move the accumulator right after it (it has no idea this is an MFMA).
+    if constexpr (QA && LAST)
+        asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\ts_nop 7\n\ts_nop 4"
+                     : "+a"(acc) : "v"(af), "a"(q));
+    else if constexpr (QA)
+        asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(af), "a"(q));
+    else if constexpr (LAST)
+        asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\ts_nop 7\n\ts_nop 4"
+                     : "+a"(acc) : "v"(af), "v"(q));
+    else
+        asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(af), "v"(q));
+}
+
+// Per-call preparation for the two-stage path, one launch:
+//   blocks [0, qblocks): 4 queries each (one wave per query): 1/||q|| (as query_prep_kernel) and the
+//     query as bf16 MFMA B-fragments in the order coarse_scan_kernel's waves load them
+//     ([256-query block][wave][16-query block][k-step][lane][8], zero padded): a fragment is one
+//     coalesced 1-KiB wave load;
+//   blocks [qblocks, ...): 256 rows each: the row's share of the combined score folded into
+//     U = t * A + B_up,  L = t * A + B_lo   with t = (q . row) / ||q||:
+//     A = 0.5 strength / ||row||,  B = 0.2 exp(-(now - ts)/3600) strength +- E_row.
+//     (Association differs from the exact epilogue by a few ulp: covered by the 1e-5 in E_cos.)
+__global__ __launch_bounds__(256) void coarse_prep_kernel(const float* __restrict__ x, int64_t nq,
+                                                          int64_t nq_pad, int64_t D, int KS,
+                                                          uint16_t* __restrict__ qhat,
+                                                          float* __restrict__ inv, int32_t* overflow,
+                                                          int qblocks, const float* __restrict__ meta,
+                                                          const float* __restrict__ inv_norm,
+                                                          int64_t N, float now, float e_cos,
+                                                          float4* __restrict__ rowc) {
+    if ((int)blockIdx.x >= qblocks) {
+        const int64_t row = ((int64_t)blockIdx.x - qblocks) * 256 + threadIdx.x;
+        if (row >= N) return;
+        const float4 m = *reinterpret_cast<const float4*>(meta + row * 4);
+        const float strength = m.x;
+        const float tw = 0.2f * expf(-(now - m.y) / 3600.0f);
+        const float err = 0.5f * e_cos * fabsf(strength);
+        const float A = 0.5f * inv_norm[row] * strength;
+        rowc[row] = make_float4(A, tw * strength + err, tw * strength - err, 0.0f);
+        return;
+    }
+    const int lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (overflow && blockIdx.x == 0 && threadIdx.x == 0) *overflow = 0;
+    if (q >= nq_pad) return;
+    const int64_t qblk = q >> 8;
+    const int wq = (int)(q >> 6) & 3, b = (int)(q >> 4) & 3, lr = (int)q & 15;
+    uint16_t* const base = qhat + ((((qblk * 4 + wq) * 4 + b) * KS) * 64 + lr) * 8;
+    float s = 0.0f;
+    for (int c = lane; c < KS * 4; c += 64) {             // chunk c: k = 8c .. 8c+7 = k-step c/4, lg c%4
+        f32x8v v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.0f;
+        const int64_t k0 = 8 * (int64_t)c;
+        if (q < nq && k0 < D) {
+            const float4 u = *reinterpret_cast<const float4*>(x + q * D + k0);      // D % 4 == 0
+            v[0] = u.x; v[1] = u.y; v[2] = u.z; v[3] = u.w;
+            if (k0 + 4 < D) {
+                const float4 w = *reinterpret_cast<const float4*>(x + q * D + k0 + 4);
+                v[4] = w.x; v[5] = w.y; v[6] = w.z; v[7] = w.w;
+            }
+        }
+        // same accumulation order per lane as query_prep_kernel's 16-byte path is not needed:
+        // inv_q only has to be the SAME value the re-scoring stage uses (it reads this array)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s = fmaf(v[e], v[e], s);
+        *reinterpret_cast<bf16x8v*>(base + ((int64_t)(c >> 2) * 64 + (c & 3) * 16) * 8) =
+            __builtin_convertvector(v, bf16x8v);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0 && q < nq) inv[q] = 1.0f / fmaxf(sqrtf(s), 1e-12f);
+}
+
+// T[q] = k-th largest of the G group maxima: one wave per query, PER keys per lane in registers;
+// the key is built bit by bit from the top (largest T with count(keys >= T) >= k).  Also zeroes
+// the candidate counters.
+template <int PER>
+__global__ __launch_bounds__(256) void coarse_threshold_kernel(const float* __restrict__ gmax,
+                                                               int64_t gmax_ld, int G, int k, int nq,
+                                                               uint32_t* __restrict__ thr_out,
+                                                               int32_t* __restrict__ cnt_out) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    uint32_t key[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int g = i * 64 + lane;
+        key[i] = g < G ? ord_key(gmax[(int64_t)q * gmax_ld + g]) : 0u;
+    }
+    uint32_t T = 0u;
+    for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t cand = T | (1u << bit);
+        int c = 0;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) c += __popcll(__ballot(key[i] >= cand));
+        if (c >= k) T = cand;
+    }
+    if (lane == 0) {
+        thr_out[q] = T;
+        cnt_out[(int64_t)q * CNT_STRIDE] = 0;
+    }
+}
+
+template <int KS, int MODE>
+__global__ __launch_bounds__(CS_THREADS) void coarse_scan_kernel(const CoarseArgs a) {
+    static_assert(KS % 2 == 0, "KS pieces are dealt 4 waves x KS/2");
+    constexpr int TILE_BYTES = KS * 2048;                  // 16 rows x KS*32 floats
+    constexpr int SLOT_BYTES = TILE_BYTES + CS_AUX_BYTES;
+    constexpr int NP = KS / 2;                             // bank pieces per wave and tile
+    constexpr int GL = NP + 1;                             // global_load_lds per wave and tile
+    extern __shared__ __attribute__((aligned(16))) char csmem[];
+    uint32_t* const s_buf = reinterpret_cast<uint32_t*>(csmem + CS_SLOTS * SLOT_BYTES);  // [CS_BUF][3]
+    __shared__ int s_nbuf;
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, lr = lane & 15, lg = lane >> 4;
+    const uint32_t D = (uint32_t)a.D;
+
+    const int64_t nqblk = (a.nq + 255) / 256;
+    const int64_t total = a.n_tiles * nqblk;
+    const int64_t lo = total * (int64_t)blockIdx.x / gridDim.x;
+    const int64_t hi = total * ((int64_t)blockIdx.x + 1) / gridDim.x;
+    if (tid == 0) s_nbuf = 0;
+
+    // reader offsets inside a k-step block: chunks 2g and 2g+1 of row lr, XOR-swizzled
+    const int sw = (lr >> 1) & 7;
+    const int off0 = (8 * lr + ((2 * lg) ^ sw)) * 16;
+    const int off1 = (8 * lr + ((2 * lg + 1) ^ sw)) * 16;
+    // loader roles: piece m = wave + 4 i -> k-step m>>1, row half m&1; lane -> row rho, 16-B chunk c
+    // (the image is swizzled by choosing WHICH chunk a lane fetches: LDS-DMA writes lane-linear).
+    // Columns beyond D re-read the row's last 16 bytes: finite data times the queries' zero padding.
+    uint32_t voff[NP];                                     // byte offset from the tile's first row
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int m = wave + 4 * i;
+        const int s = m >> 1, half = m & 1;
+        const uint32_t rho = 8 * half + (lane >> 3);
+        const uint32_t cch = (lane & 7) ^ ((rho >> 1) & 7);
+        uint32_t kf = 32 * s + 4 * cch;
+        if (kf >= D) kf = D - 4;
+        voff[i] = (rho * D + kf) * 4u;
+    }
+
+    auto tile_row0 = [&](int64_t j) -> int64_t {
+        if (MODE == CS_MODE_SAMPLE) return ((j >> 3) * a.tile_step) * 128 + (j & 7) * 16;
+        return j * 16;
+    };
+    auto issue = [&](int64_t j, int slot) {
+        char* const sb = csmem + slot * SLOT_BYTES;
+        const int64_t r0 = tile_row0(j);
+        const char* const base = reinterpret_cast<const char*>(a.bank + r0 * (int64_t)D);
+        if (r0 + CS_ROWS <= a.N) {
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                const int m = wave + 4 * i;
+                glds16(reinterpret_cast<const float*>(base + voff[i]), sb + (m >> 1) * 2048 + (m & 1) * 1024);
+            }
+        } else {                                           // last, partial tile: clamp the row
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                const int m = wave + 4 * i;
+                const uint32_t rho = 8 * (m & 1) + (lane >> 3);
+                const uint32_t last = (uint32_t)(a.N - 1 - r0);
+                const uint32_t o = rho <= last ? voff[i] : voff[i] - (rho - last) * D * 4u;
+                glds16(reinterpret_cast<const float*>(base + o), sb + (m >> 1) * 2048 + (m & 1) * 1024);
+            }
+        }
+        {   // row constants (every wave issues the same piece: uniform vmcnt, same bytes)
+            int64_t row = r0 + (lane & 15);
+            if (row >= a.N) row = a.N - 1;
+            glds16(reinterpret_cast<const float*>(a.rowc + row), sb + TILE_BYTES);
+        }
+    };
+
+    int64_t c = lo;
+    while (c < hi) {
+        const int64_t qblk = c / a.n_tiles, j0 = c - qblk * a.n_tiles;
+        const int64_t seg = (hi - c) < (a.n_tiles - j0) ? (hi - c) : (a.n_tiles - j0);
+        c += seg;
+        const int qoff = (int)qblk * 256 + wave * 64;      // this wave's first query
+
+        // ---- stationary operand: 64 queries of this wave as bf16 B-fragments ----
+        // one 16-byte load per fragment, all in flight at once, landing in their final registers
+        bf16x8v qf[CS_QB][KS];
+        float iq[CS_QB], thrf[CS_QB];
+#pragma unroll
+        for (int b = 0; b < CS_QB; ++b) {
+            const int q = qoff + 16 * b + lr;
+            const bool vq = q < a.nq;
+            iq[b] = vq ? a.inv_q[q] : 0.0f;
+            thrf[b] = (MODE == CS_MODE_FILTER && vq) ? ord_unkey(a.thr[q]) : INFINITY;
+            const uint16_t* qp = a.qhat + ((((qblk * 4 + wave) * 4 + b) * KS) * 64 + lane) * 8;
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+                qf[b][s] = *reinterpret_cast<const bf16x8v*>(qp + (int64_t)s * 512);
+        }
+#pragma unroll
+        for (int b = 0; b < CS_QB; ++b) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                // pin each fragment in its register file (see mfma_bf16_q)
+                if (b * KS + s < CS_QA) asm volatile("" : "=a"(qf[b][s]) : "0"(qf[b][s]));
+                else asm volatile("" : "=v"(qf[b][s]) : "0"(qf[b][s]));
+            }
+        }
+        // all ordinary loads above are consumed; from here to the flush only LDS-DMA is in flight
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+        issue(j0, 0);
+        if (seg > 1) issue(j0 + 1, 1);
+        int slot = 0;
+        for (int64_t t = 0; t < seg; ++t) {
+            if (t + 1 < seg) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GL) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (t + 2 < seg && !(a.dbg & 4)) issue(j0 + t + 2, slot == 0 ? 2 : slot - 1);
+
+            const char* const sb = csmem + slot * SLOT_BYTES;
+            f32x4v acc[CS_QB];
+#pragma unroll
+            for (int b = 0; b < CS_QB; ++b)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[b][e] = 0.0f;
+            // fragment reads run two k-steps ahead of the MFMAs (one wave per SIMD: nothing else
+            // hides the LDS latency)
+            f32x4v xr[3][2];
+            if (!(a.dbg & 1)) {
+#pragma unroll
+            for (int s = 0; s < 2 && s < KS; ++s) {
+                xr[s][0] = *reinterpret_cast<const f32x4v*>(sb + s * 2048 + off0);
+                xr[s][1] = *reinterpret_cast<const f32x4v*>(sb + s * 2048 + off1);
+            }
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                if (s + 2 < KS) {
+                    xr[(s + 2) % 3][0] = *reinterpret_cast<const f32x4v*>(sb + (s + 2) * 2048 + off0);
+                    xr[(s + 2) % 3][1] = *reinterpret_cast<const f32x4v*>(sb + (s + 2) * 2048 + off1);
+                }
+                const f32x4v x0 = xr[s % 3][0], x1 = xr[s % 3][1];
+                f32x8v x;
+                x[0] = x0[0]; x[1] = x0[1]; x[2] = x0[2]; x[3] = x0[3];
+                x[4] = x1[0]; x[5] = x1[1]; x[6] = x1[2]; x[7] = x1[3];
+                const bf16x8v af = __builtin_convertvector(x, bf16x8v);
+#pragma unroll
+                for (int b = 0; b < CS_QB; ++b) {
+                    if (b * KS + s < CS_QA) {
+                        if (s == KS - 1) mfma_bf16_q<true, true>(acc[b], af, qf[b][s]);
+                        else mfma_bf16_q<true, false>(acc[b], af, qf[b][s]);
+                    } else {
+                        if (s == KS - 1) mfma_bf16_q<false, true>(acc[b], af, qf[b][s]);
+                        else mfma_bf16_q<false, false>(acc[b], af, qf[b][s]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+
+            // ---- epilogue: rows 4 lg + e of the tile, queries qoff + 16 b + lr ----
+            const int64_t r0 = tile_row0(j0 + t);
+            float gm[CS_QB];
+            unsigned bits = 0u;
+            if (!(a.dbg & 2)) {
+#pragma unroll
+            for (int b = 0; b < CS_QB; ++b) gm[b] = -INFINITY;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int rr = 4 * lg + e;
+                const float4 rc = *reinterpret_cast<const float4*>(sb + TILE_BYTES + rr * 16);
+                const bool vrow = r0 + rr < a.N;
+#pragma unroll
+                for (int b = 0; b < CS_QB; ++b) {
+                    const float tq = acc[b][e] * iq[b];
+                    if (MODE == CS_MODE_SAMPLE) {
+                        gm[b] = fmaxf(gm[b], vrow ? tq * rc.x + rc.z : -INFINITY);
+                    } else {
+                        const float up = tq * rc.x + rc.y;
+                        acc[b][e] = up;
+                        bits |= (vrow && up >= thrf[b]) ? (1u << (b * 4 + e)) : 0u;   // thrf = +inf: q >= nq
+                    }
+                }
+            }
+            }
+            if (MODE == CS_MODE_SAMPLE) {
+#pragma unroll
+                for (int b = 0; b < CS_QB; ++b) {
+                    float mx = gm[b];
+                    mx = fmaxf(mx, __shfl_xor(mx, 16));
+                    mx = fmaxf(mx, __shfl_xor(mx, 32));
+                    const int q = qoff + 16 * b + lr;
+                    if (lg == 0 && q < a.nq) a.gmax[(int64_t)q * a.gmax_ld + (j0 + t)] = mx;
+                }
+            } else if (bits != 0u) {
+                int p = atomicAdd(&s_nbuf, __popc(bits));
+#pragma unroll
+                for (int b = 0; b < CS_QB; ++b) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if ((bits >> (b * 4 + e)) & 1u) {
+                            if (p < CS_BUF) {
+                                s_buf[p * 3 + 0] = (uint32_t)(qoff + 16 * b + lr);
+                                s_buf[p * 3 + 1] = (uint32_t)(r0 + 4 * lg + e);
+                                s_buf[p * 3 + 2] = __float_as_uint(acc[b][e]);
+                            }
+                            ++p;
+                        }
+                    }
+                }
+            }
+            if (MODE == CS_MODE_FILTER && ((t & 3) == 3 || t + 1 == seg)) {
+                // uniform decision point: the count is read between two barriers
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                const int nb = s_nbuf;
+                if (t + 1 == seg || nb > CS_BUF / 2) {
+                    // flush (rare inside a span; its ordinary atomics drain the LDS-DMA ring, after
+                    // which the counted waits above are simply already satisfied)
+                    const int n = nb < CS_BUF ? nb : CS_BUF;
+                    for (int i = tid; i < n; i += CS_THREADS) {
+                        const int q = (int)s_buf[i * 3];
+                        const int p = atomicAdd(a.cnt + (int64_t)q * CNT_STRIDE, 1);
+                        if (p < a.cap) {
+                            a.cand_scores[(int64_t)q * a.cap + p] = __uint_as_float(s_buf[i * 3 + 2]);
+                            a.cand_idx[(int64_t)q * a.cap + p] = (int32_t)s_buf[i * 3 + 1];
+                        }
+                    }
+                    if (nb > CS_BUF && tid == 0)       // buffer overran: poison one counter
+                        atomicAdd(a.cnt + (int64_t)(qblk * 256) * CNT_STRIDE, a.cap + 1);
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    if (tid == 0) s_nbuf = 0;
+                }
+            }
+            slot = slot == 2 ? 0 : slot + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Refine: one workgroup per query.
+// ------------------------------------------------------------------------------------------
+struct RefineArgs {
+    const float* bank;
+    const float* inv_norm;
+    const float* meta;
+    const float* queries;
+    const float* inv_q;
+    float now, e_cos;
+    int64_t N, D;
+    int k;
+    const int32_t* cnt;
+    const float* cand_scores;   // U
+    const int32_t* cand_idx;
+    int cap;
+    int32_t idx_base;
+    float* out_scores;          // [nq][k]
+    int32_t* out_idx;
+    int32_t* overflow;
+};
+
+__global__ __launch_bounds__(RF_THREADS) void coarse_refine_kernel(const RefineArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char rsmem[];
+    // phase A: candidate arrays; phase B (aliases A): per-wave row chunks
+    float* const s_u = reinterpret_cast<float*>(rsmem);                       // [RF_CAP]
+    uint32_t* const s_l = reinterpret_cast<uint32_t*>(rsmem + RF_CAP * 4);    // [RF_CAP] ord_key(L)
+    int32_t* const s_i = reinterpret_cast<int32_t*>(rsmem + RF_CAP * 8);      // [RF_CAP]
+    __shared__ int32_t s_surv[RF_SURV];
+    __shared__ unsigned long long s_key[RF_SURV];
+    __shared__ int s_hist[256];
+    __shared__ int s_ns, s_sel_k;
+    __shared__ uint32_t s_prefix;
+
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int64_t D = a.D;
+    int n = a.cnt[(int64_t)q * CNT_STRIDE];
+    bool ovf = false;
+    const int capn = a.cap < RF_CAP ? a.cap : RF_CAP;
+    if (n > capn) { ovf = true; n = capn; }
+
+    for (int i = tid; i < n; i += RF_THREADS) {
+        const float u = a.cand_scores[(int64_t)q * a.cap + i];
+        const int32_t r = a.cand_idx[(int64_t)q * a.cap + i];
+        const float err = 0.5f * a.e_cos * fabsf(a.meta[(int64_t)r * 4]);
+        s_u[i] = u;
+        s_i[i] = r;
+        s_l[i] = ord_key(u - 2.0f * err);
+    }
+    if (tid == 0) { s_ns = 0; s_prefix = 0u; s_sel_k = a.k; }
+    __syncthreads();
+
+    // ---- T2 = k-th largest L (MSB-first 8-bit radix select); everything survives if n < k ----
+    uint32_t t2 = 0u;
+    if (n >= a.k) {
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            for (int i = tid; i < 256; i += RF_THREADS) s_hist[i] = 0;
+            __syncthreads();
+            const uint32_t prefix = s_prefix;
+            const uint32_t himask = shift == 24 ? 0u : (0xffffffffu << (shift + 8));
+            for (int i = tid; i < n; i += RF_THREADS) {
+                const uint32_t key = s_l[i];
+                if ((key & himask) == prefix) atomicAdd(&s_hist[(key >> shift) & 255], 1);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int need = s_sel_k, b = 255;
+                for (; b > 0; --b) {
+                    if (s_hist[b] >= need) break;
+                    need -= s_hist[b];
+                }
+                s_sel_k = need;
+                s_prefix = prefix | ((uint32_t)b << shift);
+            }
+            __syncthreads();
+        }
+        t2 = s_prefix;
+    }
+    // ---- survivors: U >= T2 ----
+    for (int i = tid; i < n; i += RF_THREADS) {
+        if (ord_key(s_u[i]) >= t2) {
+            const int p = atomicAdd(&s_ns, 1);
+            if (p < RF_SURV) s_surv[p] = s_i[i];
+        }
+    }
+    __syncthreads();
+    int S = s_ns;
+    if (S > RF_SURV) { ovf = true; S = RF_SURV; }
+    if (ovf && tid == 0 && a.overflow) *a.overflow = 1;
+    __syncthreads();     // candidate arrays are dead from here: rsmem is reused below
+
+    // ---- exact re-scoring: wave w takes survivors w*16 .. w*16+15 of each round of 128 ----
+    // k order of the fp32 scan (knn_scan_filter_v2): inside each group of 8 consecutive k the
+    // MFMA chain visits 0,4,1,5,2,6,3,7; D is padded with zeros to a multiple of 32.
+    constexpr int RSTRIDE = RF_KC + 4;                       // floats; 16-B aligned, conflict-free
+    float* const s_rows = reinterpret_cast<float*>(rsmem) + wave * (RF_ROWS * RSTRIDE);
+    float* const s_q = reinterpret_cast<float*>(rsmem) + 8 * (RF_ROWS * RSTRIDE);   // [Dpad]
+    const int64_t Dpad = (D + 31) / 32 * 32;
+    for (int64_t i = tid; i < Dpad; i += RF_THREADS) s_q[i] = i < D ? a.queries[(int64_t)q * D + i] : 0.0f;
+    __syncthreads();
+    const float iq = a.inv_q[q];
+    for (int base = 0; base < S; base += 8 * RF_ROWS) {
+        const int mine = base + wave * RF_ROWS;              // first survivor of this wave
+        const int cntw = (S - mine) < RF_ROWS ? (S - mine) : RF_ROWS;   // may be <= 0
+        float acc = 0.0f;
+        for (int64_t k0 = 0; k0 < Dpad; k0 += RF_KC) {
+            const int kc = (int)((Dpad - k0) < RF_KC ? (Dpad - k0) : RF_KC);
+            // cooperative load: lane -> float4 column, loop over the wave's rows
+            for (int r = 0; r < RF_ROWS; ++r) {
+                const int col = lane * 4;
+                if (col < kc) {
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (r < cntw && k0 + col < D)
+                        v = *reinterpret_cast<const float4*>(a.bank + (int64_t)s_surv[mine + r] * D + k0 + col);
+                    *reinterpret_cast<float4*>(s_rows + r * RSTRIDE + col) = v;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            if (lane < RF_ROWS) {
+                const float* rp = s_rows + lane * RSTRIDE;
+                const float* qp = s_q + k0;
+                for (int kk = 0; kk < kc; kk += 8) {
+                    const float4 b0 = *reinterpret_cast<const float4*>(rp + kk);
+                    const float4 b1 = *reinterpret_cast<const float4*>(rp + kk + 4);
+                    const float4 q0 = *reinterpret_cast<const float4*>(qp + kk);
+                    const float4 q1 = *reinterpret_cast<const float4*>(qp + kk + 4);
+                    acc = fmaf(q0.x, b0.x, acc); acc = fmaf(q1.x, b1.x, acc);
+                    acc = fmaf(q0.y, b0.y, acc); acc = fmaf(q1.y, b1.y, acc);
+                    acc = fmaf(q0.z, b0.z, acc); acc = fmaf(q1.z, b1.z, acc);
+                    acc = fmaf(q0.w, b0.w, acc); acc = fmaf(q1.w, b1.w, acc);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        if (lane < RF_ROWS && lane < cntw) {
+            const int32_t row = s_surv[mine + lane];
+            const float inv_m = a.inv_norm[row];
+            const float4 m = *reinterpret_cast<const float4*>(a.meta + (int64_t)row * 4);
+            const float tw = 0.2f * expf(-(a.now - m.y) / 3600.0f);
+            const float sim = acc * iq * inv_m;
+            const float comb = (0.5f * sim + tw) * m.x;
+            s_key[mine + lane] = ((unsigned long long)ord_key(comb) << 32) | (uint32_t)(~(uint32_t)row);
+        }
+    }
+    // ---- sort the survivors' exact keys (descending) and write the top k ----
+    int P = 64;
+    while (P < S) P <<= 1;
+    __syncthreads();
+    for (int i = S + tid; i < P; i += RF_THREADS) s_key[i] = 0ull;
+    __syncthreads();
+    for (int len = 2; len <= P; len <<= 1) {
+        for (int inc = len >> 1; inc > 0; inc >>= 1) {
+            for (int i = tid; i < P / 2; i += RF_THREADS) {
+                const int lo_i = (i / inc) * 2 * inc + (i % inc), hi_i = lo_i + inc;
+                const bool desc = ((lo_i & len) == 0);
+                const unsigned long long x = s_key[lo_i], y = s_key[hi_i];
+                if ((x < y) == desc) { s_key[lo_i] = y; s_key[hi_i] = x; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < a.k; i += RF_THREADS) {
+        const unsigned long long key = i < S ? s_key[i] : 0ull;
+        float sc = -INFINITY;
+        int32_t id = -1;
+        if (i < S) {
+            sc = ord_unkey((uint32_t)(key >> 32));
+            id = (int32_t)(~(uint32_t)key) + a.idx_base;
+        }
+        a.out_scores[(int64_t)q * a.k + i] = sc;
+        a.out_idx[(int64_t)q * a.k + i] = id;
+    }
+}
+
+inline bool coarse_eligible(const float* bank, const float* queries, const float* loc_q,
+                            const float* centroids, int64_t N, int64_t D, int k, int flags) {
+    static const bool off = getenv("AURA_KNN_NO_COARSE") != nullptr;
+    if (off || (flags & (AURA_KNN_FORCE_DENSE | AURA_KNN_FP32_SCAN))) return false;
+    if (loc_q || centroids) return false;
+    if (N < COARSE_MIN_ROWS || D > 768 || (D & 3) || k > COARSE_MAX_K) return false;
+    if ((reinterpret_cast<uintptr_t>(bank) & 15) || (reinterpret_cast<uintptr_t>(queries) & 15)) return false;
+    return true;
+}
+
+template <int KS>
+inline int launch_coarse(const CoarseArgs& a, int mode, int grid, hipStream_t s) {
+    const size_t lds = (size_t)CS_SLOTS * (KS * 2048 + CS_AUX_BYTES) + (size_t)CS_BUF * 12;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(coarse_scan_kernel<KS, CS_MODE_SAMPLE>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(coarse_scan_kernel<KS, CS_MODE_FILTER>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return AURA_E_LAUNCH;
+        attr_set = true;
+    }
+    if (mode == CS_MODE_SAMPLE)
+        hipLaunchKernelGGL((coarse_scan_kernel<KS, CS_MODE_SAMPLE>), dim3(grid), dim3(CS_THREADS), lds, s, a);
+    else
+        hipLaunchKernelGGL((coarse_scan_kernel<KS, CS_MODE_FILTER>), dim3(grid), dim3(CS_THREADS), lds, s, a);
+    return check_launch();
+}
+
+inline int dispatch_coarse(const CoarseArgs& a, int mode, int grid, hipStream_t s) {
+    const int64_t ks = (a.D + 31) / 32;
+    if (ks <= 8) return launch_coarse<8>(a, mode, grid, s);
+    if (ks <= 16) return launch_coarse<16>(a, mode, grid, s);
+    return launch_coarse<24>(a, mode, grid, s);
+}

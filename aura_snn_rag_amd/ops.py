@@ -256,8 +256,8 @@ def _workspace(device, nbytes: int) -> torch.Tensor:
 
 def knn_search(bank, inv_norm, meta, queries, k: int, now: float, count: Optional[int] = None,
                loc=None, q_loc=None, idx_base: int = 0, force_dense: bool = False,
-               centroids=None, nprobe: int = 0, check_overflow: bool = True
-               ) -> Tuple[torch.Tensor, torch.Tensor]:
+               centroids=None, nprobe: int = 0, check_overflow: bool = True,
+               fp32_scan: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     """Exact batched recall over rows [0, count) -> (scores [nq, k] fp32, idx [nq, k] int32).
 
     ``centroids`` (256 x D) + ``nprobe`` switches on the reference's centroid-candidate
@@ -307,7 +307,7 @@ def knn_search(bank, inv_norm, meta, queries, k: int, now: float, count: Optiona
                                    base, nbytes, flags, _p(ovf), _p(centroids), nprobe, _stream()),
               "aura_knn_search_ex")
 
-    run(_lib.KNN_FORCE_DENSE if force_dense else 0)
+    run(_lib.KNN_FORCE_DENSE if force_dense else (_lib.KNN_FP32_SCAN if fp32_scan else 0))
     if check_overflow and not force_dense and int(ovf.item()) != 0:
         run(_lib.KNN_FORCE_DENSE)
     return out_s, out_i

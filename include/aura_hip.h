@@ -132,6 +132,11 @@ int aura_knn_search(const float* bank, const float* inv_norm, const float* meta,
  * int32, set to 1 if a candidate list overflowed -- the caller must then re-run with
  * AURA_KNN_FORCE_DENSE; may be NULL). */
 #define AURA_KNN_FORCE_DENSE 1
+/* AURA_KNN_FP32_SCAN: score every row on the fp32 matrix pipe.  Without it, large banks
+ * (>= 16384 rows, D <= 768, D % 4 == 0, no location term / centroid mask, k <= 256) are first
+ * filtered by a bf16 scan whose error is bounded, and only rows that can still reach the top k are
+ * re-scored in fp32 with the same arithmetic: results are bit-identical either way. */
+#define AURA_KNN_FP32_SCAN 2
 int aura_knn_search_ex(const float* bank, const float* inv_norm, const float* meta,
                        const float* loc, int spatial_dims, const float* queries,
                        const float* q_loc, float now, int64_t N, int64_t D, int64_t nq, int k,
@@ -168,6 +173,8 @@ int aura_profile_end(float* ms_out_host, int max_out);
 /* Bank rows and queries scored by the most recent profiled main-scan launch (HOST pointers):
  * the units behind bench.py's algorithmic FLOP count, 2 * rows * nq * D per launch. */
 int aura_profile_last_scan(int64_t* rows_out, int64_t* nq_out);
+/* 0 = the profiled launch was the fp32 matrix scan, 1 = the bf16 prefilter scan. */
+int aura_profile_last_scan_kind(void);
 
 /* Merge S per-shard top-k lists into the global top-k (the step after the RCCL all-gather,
  * SURVEY.md section 8e).  in_scores/in_idx: [S][nq][k]; out: [nq][k]; ties -> lower index. */
