@@ -1626,8 +1626,9 @@ inline int run_coarse_pass(const float* bank, const float* inv_norm, const float
     int rc;
     // sample: strided 128-row logical tiles (8 coarse tiles each), sized as for the fp32 path
     int64_t sample_rows = (int64_t)k * N / 512;
-    if (sample_rows < 8192) sample_rows = 8192;
-    if (sample_rows < (int64_t)k * 48) sample_rows = (int64_t)k * 48;
+    int64_t floor_rows = N / 8 < 8192 ? N / 8 : 8192;
+    if (floor_rows < (int64_t)k * 48) floor_rows = (int64_t)k * 48;
+    if (sample_rows < floor_rows) sample_rows = floor_rows;
     const int64_t ntiles128 = N / 128;                       // whole logical tiles only
     int64_t n_sample = (sample_rows + 127) / 128;
     if (n_sample * 8 > THR_MAX_GROUPS) n_sample = THR_MAX_GROUPS / 8;
@@ -1652,7 +1653,7 @@ inline int run_coarse_pass(const float* bank, const float* inv_norm, const float
     c.dbg = cs_dbg;
     c.N = N; c.D = D; c.nq = nqb;
     c.thr = w.thr; c.cnt = w.cnt; c.cand_scores = w.cand_scores; c.cand_idx = w.cand_idx;
-    c.cap = w.cap;
+    c.cap = w.cap; c.overflow = overflow_out;
     const int cus = device_cu_count();
 
     c.n_tiles = G; c.tile_step = tile_step; c.n_sample = (int)n_sample;

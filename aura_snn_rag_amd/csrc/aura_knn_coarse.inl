@@ -45,7 +45,7 @@ constexpr int CS_SLOTS = 3;
 constexpr int CS_AUX_BYTES = 1024;       // per slot: row constants (64 lanes x 16 B, first 16 used)
 constexpr int CS_BUF = 832;              // candidate entries buffered per workgroup
 constexpr int CS_MODE_SAMPLE = 0, CS_MODE_FILTER = 1;
-constexpr int64_t COARSE_MIN_ROWS = 16384;
+constexpr int64_t COARSE_MIN_ROWS = 8192;
 constexpr int COARSE_MAX_K = 256;
 constexpr int RF_THREADS = 512;
 constexpr int RF_CAP = 4096;             // candidates per query the refine kernel holds in LDS
@@ -69,6 +69,7 @@ struct CoarseArgs {
     float* cand_scores;      // [nq][cap]: U
     int32_t* cand_idx;
     int cap;
+    int32_t* overflow;       // set to 1 when a workgroup's candidate buffer overran (results invalid)
     int dbg;                 // AURA_CS_DBG timing ablations (results invalid when non-zero)
 };
 
@@ -87,6 +88,33 @@ __device__ __forceinline__ void glds4(const float* g, char* lds_wave_base) {
 // AGPRs (the hardware reads srcB from either file), the rest in VGPRs.  Hazards the compiler
 // would cover for its own MFMAs are covered by the s_nop statements around the groups.
 constexpr int CS_QA = 58;   // fragments (4 registers each) kept in AGPRs, next to the 16 accumulators
+// LDS accesses of the steady-state loop that are NOT the MFMA fragments go through inline asm:
+// hipcc puts "s_waitcnt vmcnt(0)" in front of an ordinary LDS access it cannot separate from an
+// outstanding LDS-DMA (global_load_lds) -- which would drain the two-tile prefetch every tile.
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+}
+__device__ __forceinline__ void lds_read4x16(uint32_t addr, float4& r0, float4& r1, float4& r2, float4& r3) {
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\t"
+                 "ds_read_b128 %2, %4 offset:32\n\tds_read_b128 %3, %4 offset:48\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3) : "v"(addr) : "memory");
+}
+__device__ __forceinline__ int lds_add_rtn(uint32_t addr, int v) {
+    int r;
+    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r) : "v"(addr), "v"(v) : "memory");
+    return r;
+}
+__device__ __forceinline__ int lds_read_i32(uint32_t addr) {
+    int r;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r) : "v"(addr) : "memory");
+    return r;
+}
+__device__ __forceinline__ void lds_write3(uint32_t addr, uint32_t a0, uint32_t a1, uint32_t a2) {
+    asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %0, %2 offset:4\n\tds_write_b32 %0, %3 offset:8"
+                 :: "v"(addr), "v"(a0), "v"(a1), "v"(a2) : "memory");
+}
+
 template <bool QA, bool LAST>
 __device__ __forceinline__ void mfma_bf16_q(f32x4v& acc, const bf16x8v& af, const bf16x8v& q) {
     // s_nop 1 in front: two wait states between a VALU write of an operand register (the bf16
@@ -155,13 +183,15 @@ __global__ __launch_bounds__(256) void coarse_prep_kernel(const float* __restric
                 v[4] = w.x; v[5] = w.y; v[6] = w.z; v[7] = w.w;
             }
         }
-        // same accumulation order per lane as query_prep_kernel's 16-byte path is not needed:
-        // inv_q only has to be the SAME value the re-scoring stage uses (it reads this array)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) s = fmaf(v[e], v[e], s);
         *reinterpret_cast<bf16x8v*>(base + ((int64_t)(c >> 2) * 64 + (c & 3) * 16) * 8) =
             __builtin_convertvector(v, bf16x8v);
     }
+    // 1/||q|| with query_prep_kernel's arithmetic (the re-scored results must not depend on the path)
+    if (q < nq)
+        for (int64_t i = lane * 4; i < D; i += 256) {
+            const float4 u = *reinterpret_cast<const float4*>(x + q * D + i);
+            s = fmaf(u.x, u.x, s); s = fmaf(u.y, u.y, s); s = fmaf(u.z, u.z, s); s = fmaf(u.w, u.w, s);
+        }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
     if (lane == 0 && q < nq) inv[q] = 1.0f / fmaxf(sqrtf(s), 1e-12f);
@@ -362,10 +392,12 @@ __global__ __launch_bounds__(CS_THREADS) void coarse_scan_kernel(const CoarseArg
             if (!(a.dbg & 2)) {
 #pragma unroll
             for (int b = 0; b < CS_QB; ++b) gm[b] = -INFINITY;
+            float4 rcv[4];                                   // constants of rows 4 lg .. 4 lg + 3
+            lds_read4x16(lds_addr(sb + TILE_BYTES) + lg * 64, rcv[0], rcv[1], rcv[2], rcv[3]);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int rr = 4 * lg + e;
-                const float4 rc = *reinterpret_cast<const float4*>(sb + TILE_BYTES + rr * 16);
+                const float4 rc = rcv[e];
                 const bool vrow = r0 + rr < a.N;
 #pragma unroll
                 for (int b = 0; b < CS_QB; ++b) {
@@ -390,28 +422,27 @@ __global__ __launch_bounds__(CS_THREADS) void coarse_scan_kernel(const CoarseArg
                     if (lg == 0 && q < a.nq) a.gmax[(int64_t)q * a.gmax_ld + (j0 + t)] = mx;
                 }
             } else if (bits != 0u) {
-                int p = atomicAdd(&s_nbuf, __popc(bits));
+                int p = lds_add_rtn(lds_addr(&s_nbuf), __popc(bits));
+                const uint32_t bufa = lds_addr(s_buf);
 #pragma unroll
                 for (int b = 0; b < CS_QB; ++b) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         if ((bits >> (b * 4 + e)) & 1u) {
-                            if (p < CS_BUF) {
-                                s_buf[p * 3 + 0] = (uint32_t)(qoff + 16 * b + lr);
-                                s_buf[p * 3 + 1] = (uint32_t)(r0 + 4 * lg + e);
-                                s_buf[p * 3 + 2] = __float_as_uint(acc[b][e]);
-                            }
+                            if (p < CS_BUF)
+                                lds_write3(bufa + p * 12, (uint32_t)(qoff + 16 * b + lr),
+                                           (uint32_t)(r0 + 4 * lg + e), __float_as_uint(acc[b][e]));
                             ++p;
                         }
                     }
                 }
             }
-            if (MODE == CS_MODE_FILTER && ((t & 3) == 3 || t + 1 == seg)) {
+            if (MODE == CS_MODE_FILTER && ((t & 1) == 1 || t + 1 == seg)) {
                 // uniform decision point: the count is read between two barriers
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
-                const int nb = s_nbuf;
+                const int nb = __builtin_amdgcn_readfirstlane(lds_read_i32(lds_addr(&s_nbuf)));
                 if (t + 1 == seg || nb > CS_BUF / 2) {
                     // flush (rare inside a span; its ordinary atomics drain the LDS-DMA ring, after
                     // which the counted waits above are simply already satisfied)
@@ -424,11 +455,12 @@ __global__ __launch_bounds__(CS_THREADS) void coarse_scan_kernel(const CoarseArg
                             a.cand_idx[(int64_t)q * a.cap + p] = (int32_t)s_buf[i * 3 + 1];
                         }
                     }
-                    if (nb > CS_BUF && tid == 0)       // buffer overran: poison one counter
-                        atomicAdd(a.cnt + (int64_t)(qblk * 256) * CNT_STRIDE, a.cap + 1);
+                    if (nb > CS_BUF && tid == 0 && a.overflow) *a.overflow = 1;   // entries were dropped
                     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_s_barrier();                  // every wave has read nb / the entries
                     if (tid == 0) s_nbuf = 0;
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();                  // ... and sees the reset before it appends
                 }
             }
             slot = slot == 2 ? 0 : slot + 1;
@@ -462,13 +494,14 @@ struct RefineArgs {
 
 __global__ __launch_bounds__(RF_THREADS) void coarse_refine_kernel(const RefineArgs a) {
     extern __shared__ __attribute__((aligned(16))) char rsmem[];
-    // phase A: candidate arrays; phase B (aliases A): per-wave row chunks
+    // phase A: candidate arrays; phase B (aliases A): per-wave row chunks + the query
     float* const s_u = reinterpret_cast<float*>(rsmem);                       // [RF_CAP]
     uint32_t* const s_l = reinterpret_cast<uint32_t*>(rsmem + RF_CAP * 4);    // [RF_CAP] ord_key(L)
     int32_t* const s_i = reinterpret_cast<int32_t*>(rsmem + RF_CAP * 8);      // [RF_CAP]
     __shared__ int32_t s_surv[RF_SURV];
     __shared__ unsigned long long s_key[RF_SURV];
     __shared__ int s_hist[256];
+    __shared__ int s_wsum[4];
     __shared__ int s_ns, s_sel_k;
     __shared__ uint32_t s_prefix;
 
@@ -491,27 +524,39 @@ __global__ __launch_bounds__(RF_THREADS) void coarse_refine_kernel(const RefineA
     if (tid == 0) { s_ns = 0; s_prefix = 0u; s_sel_k = a.k; }
     __syncthreads();
 
-    // ---- T2 = k-th largest L (MSB-first 8-bit radix select); everything survives if n < k ----
+    // ---- T2 = k-th largest L: MSB-first 8-bit radix select, the digit found by a parallel suffix
+    //      scan of the 256-bin histogram; everything survives if n < k ----
     uint32_t t2 = 0u;
     if (n >= a.k) {
         for (int shift = 24; shift >= 0; shift -= 8) {
-            for (int i = tid; i < 256; i += RF_THREADS) s_hist[i] = 0;
+            if (tid < 256) s_hist[tid] = 0;
             __syncthreads();
             const uint32_t prefix = s_prefix;
+            const int need = s_sel_k;
             const uint32_t himask = shift == 24 ? 0u : (0xffffffffu << (shift + 8));
             for (int i = tid; i < n; i += RF_THREADS) {
                 const uint32_t key = s_l[i];
                 if ((key & himask) == prefix) atomicAdd(&s_hist[(key >> shift) & 255], 1);
             }
             __syncthreads();
-            if (tid == 0) {
-                int need = s_sel_k, b = 255;
-                for (; b > 0; --b) {
-                    if (s_hist[b] >= need) break;
-                    need -= s_hist[b];
+            int h = 0, v = 0;
+            if (tid < 256) {
+                h = s_hist[tid];
+                v = h;                                   // -> sum of bins tid .. end of this wave
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int o = __shfl_down(v, off);
+                    if (lane + off < 64) v += o;
                 }
-                s_sel_k = need;
-                s_prefix = prefix | ((uint32_t)b << shift);
+                if (lane == 0) s_wsum[wave] = v;
+            }
+            __syncthreads();
+            if (tid < 256) {
+                for (int w2 = wave + 1; w2 < 4; ++w2) v += s_wsum[w2];   // keys with digit >= tid
+                if (v >= need && v - h < need) {          // exactly one bin satisfies this
+                    s_sel_k = need - (v - h);
+                    s_prefix = prefix | ((uint32_t)tid << shift);
+                }
             }
             __syncthreads();
         }
@@ -543,24 +588,33 @@ __global__ __launch_bounds__(RF_THREADS) void coarse_refine_kernel(const RefineA
     for (int base = 0; base < S; base += 8 * RF_ROWS) {
         const int mine = base + wave * RF_ROWS;              // first survivor of this wave
         const int cntw = (S - mine) < RF_ROWS ? (S - mine) : RF_ROWS;   // may be <= 0
+        if (cntw <= 0) continue;                             // wave-uniform
+        const float* rowp[RF_ROWS];
+#pragma unroll
+        for (int r = 0; r < RF_ROWS; ++r)
+            rowp[r] = r < cntw ? a.bank + (int64_t)s_surv[mine + r] * D + lane * 4 : nullptr;
+        float4 pre[RF_ROWS];
+        auto fetch = [&](int64_t k0) {                       // chunk [k0, k0+256): lane -> 16 bytes
+#pragma unroll
+            for (int r = 0; r < RF_ROWS; ++r) {
+                pre[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (rowp[r] && k0 + lane * 4 < D) pre[r] = *reinterpret_cast<const float4*>(rowp[r] + k0);
+            }
+        };
         float acc = 0.0f;
+        fetch(0);
         for (int64_t k0 = 0; k0 < Dpad; k0 += RF_KC) {
             const int kc = (int)((Dpad - k0) < RF_KC ? (Dpad - k0) : RF_KC);
-            // cooperative load: lane -> float4 column, loop over the wave's rows
-            for (int r = 0; r < RF_ROWS; ++r) {
-                const int col = lane * 4;
-                if (col < kc) {
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (r < cntw && k0 + col < D)
-                        v = *reinterpret_cast<const float4*>(a.bank + (int64_t)s_surv[mine + r] * D + k0 + col);
-                    *reinterpret_cast<float4*>(s_rows + r * RSTRIDE + col) = v;
-                }
-            }
+#pragma unroll
+            for (int r = 0; r < RF_ROWS; ++r)
+                *reinterpret_cast<float4*>(s_rows + r * RSTRIDE + lane * 4) = pre[r];
+            if (k0 + RF_KC < Dpad) fetch(k0 + RF_KC);        // next chunk flies during the chain
             __builtin_amdgcn_wave_barrier();
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (lane < RF_ROWS) {
                 const float* rp = s_rows + lane * RSTRIDE;
                 const float* qp = s_q + k0;
+#pragma unroll 4
                 for (int kk = 0; kk < kc; kk += 8) {
                     const float4 b0 = *reinterpret_cast<const float4*>(rp + kk);
                     const float4 b1 = *reinterpret_cast<const float4*>(rp + kk + 4);
@@ -575,7 +629,7 @@ __global__ __launch_bounds__(RF_THREADS) void coarse_refine_kernel(const RefineA
             __builtin_amdgcn_wave_barrier();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
-        if (lane < RF_ROWS && lane < cntw) {
+        if (lane < cntw) {
             const int32_t row = s_surv[mine + lane];
             const float inv_m = a.inv_norm[row];
             const float4 m = *reinterpret_cast<const float4*>(a.meta + (int64_t)row * 4);
@@ -585,33 +639,20 @@ __global__ __launch_bounds__(RF_THREADS) void coarse_refine_kernel(const RefineA
             s_key[mine + lane] = ((unsigned long long)ord_key(comb) << 32) | (uint32_t)(~(uint32_t)row);
         }
     }
-    // ---- sort the survivors' exact keys (descending) and write the top k ----
-    int P = 64;
-    while (P < S) P <<= 1;
     __syncthreads();
-    for (int i = S + tid; i < P; i += RF_THREADS) s_key[i] = 0ull;
-    __syncthreads();
-    for (int len = 2; len <= P; len <<= 1) {
-        for (int inc = len >> 1; inc > 0; inc >>= 1) {
-            for (int i = tid; i < P / 2; i += RF_THREADS) {
-                const int lo_i = (i / inc) * 2 * inc + (i % inc), hi_i = lo_i + inc;
-                const bool desc = ((lo_i & len) == 0);
-                const unsigned long long x = s_key[lo_i], y = s_key[hi_i];
-                if ((x < y) == desc) { s_key[lo_i] = y; s_key[hi_i] = x; }
-            }
-            __syncthreads();
+    // ---- rank the survivors' exact keys (all distinct) and write the top k, sorted ----
+    for (int i = tid; i < S; i += RF_THREADS) {
+        const unsigned long long mine = s_key[i];
+        int rank = 0;
+        for (int j2 = 0; j2 < S; ++j2) rank += s_key[j2] > mine ? 1 : 0;
+        if (rank < a.k) {
+            a.out_scores[(int64_t)q * a.k + rank] = ord_unkey((uint32_t)(mine >> 32));
+            a.out_idx[(int64_t)q * a.k + rank] = (int32_t)(~(uint32_t)mine) + a.idx_base;
         }
     }
-    for (int i = tid; i < a.k; i += RF_THREADS) {
-        const unsigned long long key = i < S ? s_key[i] : 0ull;
-        float sc = -INFINITY;
-        int32_t id = -1;
-        if (i < S) {
-            sc = ord_unkey((uint32_t)(key >> 32));
-            id = (int32_t)(~(uint32_t)key) + a.idx_base;
-        }
-        a.out_scores[(int64_t)q * a.k + i] = sc;
-        a.out_idx[(int64_t)q * a.k + i] = id;
+    for (int i = S + tid; i < a.k; i += RF_THREADS) {       // fewer than k rows can score (never when k <= N)
+        a.out_scores[(int64_t)q * a.k + i] = -INFINITY;
+        a.out_idx[(int64_t)q * a.k + i] = -1;
     }
 }
 

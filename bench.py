@@ -262,8 +262,9 @@ def main():
     q = torch.cat([bank[pick.to(dev)] + 0.05 * torch.randn(nq // 2, D, generator=g).to(dev),
                    torch.randn(nq - nq // 2, D, generator=g).to(dev)]).contiguous()
 
-    def local_search(qq, kk, check=False):
-        return ops.knn_search(bank, inv, meta, qq, kk, now, count=rows, idx_base=r0, check_overflow=check)
+    def local_search(qq, kk, check=False, fp32_scan=False):
+        return ops.knn_search(bank, inv, meta, qq, kk, now, count=rows, idx_base=r0, check_overflow=check,
+                              fp32_scan=fp32_scan)
 
     recall = ShardedRecall(local_search, ops.topk_merge)
 
@@ -300,39 +301,75 @@ def main():
 
     total_q = nq * world * args.steps
     value = total_q / elapsed
-    # dominant kernel: main MFMA scan; algorithmic FLOP per launch = 2 * nq_scanned * rows_scanned * D
-    kernel_ms = sorted(buf[j] for j in range(nprof))
-    roof = None
-    if nprof > 0:
-        avg_ms = sum(kernel_ms) / nprof
+    # dominant kernel of the default (two-stage) path: the bf16 prefilter scan, which reads the bank
+    # once -> HBM roofline; algorithmic bytes per launch = rows * (D*4 + 16 B of row constants).
+    # (Shards below 8192 rows, D > 768 etc. run the fp32 matrix scan instead: MFMA roofline.)
+    def roofline_of(buf_ms, n, steps):
+        if n <= 0:
+            return None
+        avg_ms = sum(buf_ms[j] for j in range(n)) / n
         rows_c, nq_c = ctypes.c_int64(0), ctypes.c_int64(0)
         lib.aura_profile_last_scan(ctypes.byref(rows_c), ctypes.byref(nq_c))
         scanned_rows, nq_launch = rows_c.value, nq_c.value
-        flop = 2.0 * nq_launch * scanned_rows * D        # algorithmic FLOP of ONE main-scan launch
+        flop = 2.0 * nq_launch * scanned_rows * D
         tf = flop / (avg_ms * 1e-3) / 1e12
-        roof = {"bound": "mfma",
-                "kernel": "knn_scan_filter_v2 (v_mfma_f32_32x32x2_f32, fp32 in / fp32 acc)",
-                "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF,
-                "traffic": None, "avg_kernel_ms": avg_ms, "launches_timed": nprof,
-                "rows_per_launch": scanned_rows, "queries_per_launch": nq_launch,
-                "algorithmic_flop_per_launch": flop,
-                "algorithmic_bytes_per_launch": scanned_rows * (D * 4 + 24) + nq_launch * D * 4,
-                "hbm_gbs_at_kernel": (scanned_rows * D * 4) / (avg_ms * 1e-3) / 1e9,
-                "launches_per_step": nprof / args.steps}
+        common = {"traffic": None, "avg_kernel_ms": avg_ms, "launches_timed": n,
+                  "rows_per_launch": scanned_rows, "queries_per_launch": nq_launch,
+                  "launches_per_step": n / steps}
+        if lib.aura_profile_last_scan_kind() == 1:
+            nbytes = scanned_rows * (D * 4 + 16)
+            gbs = nbytes / (avg_ms * 1e-3) / 1e9
+            return dict(common, bound="hbm",
+                        kernel="coarse_scan_kernel<KS,FILTER> (bank rows streamed once by global_load_lds, "
+                               "v_mfma_f32_16x16x32_bf16 against register-resident query fragments)",
+                        achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS,
+                        algorithmic_bytes_per_launch=nbytes, pmc_key="coarse_scan_kernel<24, 1>",
+                        bf16_tflops_at_kernel=tf, bf16_frac_of_2500=tf / 2500.0)
+        return dict(common, bound="mfma",
+                    kernel="knn_scan_filter_v2 (v_mfma_f32_32x32x2_f32, fp32 in / fp32 acc)",
+                    achieved=tf, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=tf / MFMA_F32_PEAK_TF,
+                    algorithmic_flop_per_launch=flop, pmc_key="knn_scan_filter_v2<true, true>",
+                    algorithmic_bytes_per_launch=scanned_rows * (D * 4 + 24) + nq_launch * D * 4,
+                    hbm_gbs_at_kernel=(scanned_rows * D * 4) / (avg_ms * 1e-3) / 1e9)
 
-    # HBM traffic of the dominant kernel comes from a separate rocprofv3 --pmc pass (PMC and
-    # timing runs must not be mixed); the committed per-dispatch summary is reported here with the
-    # gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE counts half of a wide streaming read)
-    if roof is not None:
-        pmc = os.path.join(ROOT, "profiles", "r01_knn_pmc_per_dispatch.json")
-        if os.path.exists(pmc) and args.bank_rows == 100_000 and world == 1:
-            try:
-                d = json.load(open(pmc)).get("knn_scan_filter_v2<true, true>", {})
-                if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
-                    roof["traffic"] = (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0
-                    roof["traffic_source"] = "profiles/r01_pmc_per_dispatch.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)"
-            except Exception:
-                pass
+    def add_traffic(roof):
+        # HBM traffic of the dominant kernel comes from a separate rocprofv3 --pmc pass (PMC and timing
+        # runs must not be mixed); the committed per-dispatch summary is reported with the gfx950
+        # correction of MI355X_MICROARCH.md (FETCH_SIZE counts half of a wide streaming read)
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_per_dispatch.json")
+        if roof is None or not os.path.exists(pmc) or args.bank_rows != 100_000 or world != 1:
+            return
+        try:
+            d = json.load(open(pmc)).get(roof["pmc_key"], {})
+            if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+                roof["traffic"] = (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0
+                roof["traffic_source"] = ("profiles/r01_pmc_per_dispatch.json (rocprofv3 --pmc FETCH_SIZE / "
+                                          "WRITE_SIZE, bytes per launch)")
+        except Exception:
+            pass
+
+    roof = roofline_of(buf, nprof, args.steps)
+    add_traffic(roof)
+
+    # the all-fp32 scan of the same workload (AURA_KNN_FP32_SCAN): same results bit for bit, bound by
+    # the fp32 matrix pipe; kept as a second measured line
+    fp32_line = None
+    if rank == 0 and world == 1 and roof is not None and roof["bound"] == "hbm":
+        for _ in range(3):
+            local_search(q, k, fp32_scan=True)
+        torch.cuda.synchronize()
+        lib.aura_profile_begin(max(1, args.steps * 4))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            local_search(q, k, fp32_scan=True)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t1
+        buf2 = (ctypes.c_float * (args.steps * 4))()
+        n2 = lib.aura_profile_end(buf2, args.steps * 4)
+        r2 = roofline_of(buf2, n2, args.steps)
+        add_traffic(r2)
+        fp32_line = {"retrievals_per_s": nq * args.steps / el, "ms_per_step": el / args.steps * 1e3, "roofline": r2}
 
     out = {
         "metric": "retrievals/sec", "value": value, "unit": "retrievals/s", "n_gpus": world,
@@ -341,12 +378,16 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"episodic cosine-kNN recall: {args.bank_rows}x{D} fp32 bank "
                                f"({'row-sharded over %d ranks' % world if world > 1 else 'one GPU'}), "
-                               f"{nq}-query batch per rank, top-{k}, exact fp32 scores",
+                               f"{nq}-query batch per rank, top-{k}, exact fp32 scores (bf16 matrix-core "
+                               f"prefilter with a proven error bound + fp32 re-scoring of the survivors: "
+                               f"rows and score bits identical to the all-fp32 scan)",
                    "bank_rows": args.bank_rows, "dim": D, "queries_per_rank": nq, "k": k,
                    "parallelism": f"bank-sharded x{world}" if world > 1 else "single"},
         "planted_neighbours_found": planted_ok,
         "roofline": roof,
     }
+    if fp32_line is not None:
+        out["fp32_scan_only"] = fp32_line
     if rank == 0 and world == 1 and not args.no_secondary:
         out["secondary"] = secondary_neurons(dev)
         out["secondary"]["centroid_index_recall"] = centroid_index_recall(dev, bank, inv, meta, q, k, now)

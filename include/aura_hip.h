@@ -133,7 +133,7 @@ int aura_knn_search(const float* bank, const float* inv_norm, const float* meta,
  * AURA_KNN_FORCE_DENSE; may be NULL). */
 #define AURA_KNN_FORCE_DENSE 1
 /* AURA_KNN_FP32_SCAN: score every row on the fp32 matrix pipe.  Without it, large banks
- * (>= 16384 rows, D <= 768, D % 4 == 0, no location term / centroid mask, k <= 256) are first
+ * (>= 8192 rows, D <= 768, D % 4 == 0, no location term / centroid mask, k <= 256) are first
  * filtered by a bf16 scan whose error is bounded, and only rows that can still reach the top k are
  * re-scored in fp32 with the same arithmetic: results are bit-identical either way. */
 #define AURA_KNN_FP32_SCAN 2

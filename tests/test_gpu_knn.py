@@ -373,3 +373,63 @@ def test_ivf_equals_masked_full_scan(dev, N, D, nq, k):
     hf.create_episodic_memories([f"x{i}" for i in range(5)], extra)
     s2, r2 = hf.recall_batch(extra[2:3].to(dev), k=1, now=now)
     assert hf._idx_to_id[int(r2[0, 0])] == "x2"
+
+
+# ----------------------------------------------------------------------------------------------
+# Two-stage recall (bf16 prefilter + fp32 re-scoring, banks >= 16384 rows): must return exactly what
+# the fp32 scan returns -- rows AND score bits -- on every shape, and fall back when its lists overflow.
+# ----------------------------------------------------------------------------------------------
+def _clustered(N, D, g, n_centres=40, spread=0.25):
+    c = torch.randn(n_centres, D, generator=g)
+    return c[torch.randint(0, n_centres, (N,), generator=g)] + spread * torch.randn(N, D, generator=g)
+
+
+@pytest.mark.parametrize("N,D,nq,k,kind", [
+    (16384, 768, 256, 32, "gauss"), (16385, 32, 5, 3, "gauss"), (20011, 200, 37, 5, "gauss"),
+    (33000, 100, 300, 17, "cluster"), (50000, 512, 100, 10, "gauss"), (40000, 260, 64, 256, "cluster"),
+    (100000, 768, 1, 5, "gauss"), (65536, 516, 700, 32, "cluster"), (30000, 700, 256, 64, "gauss"),
+    (25000, 4, 40, 8, "gauss"), (120000, 64, 2300, 10, "cluster"),
+])
+def test_two_stage_equals_fp32_scan(dev, N, D, nq, k, kind):
+    g = torch.Generator().manual_seed(N * 7 + D)
+    bank = _clustered(N, D, g) if kind == "cluster" else torch.randn(N, D, generator=g)
+    bank = bank * (0.25 + 2.0 * torch.rand(N, 1, generator=g))
+    bank[torch.randint(0, N, (5,), generator=g)] = 0.0                 # zero rows: inv_norm = 1e12 clamp
+    meta = _meta(N, g, decayed=True, spread_ts=True)
+    q = _queries(bank, nq, g)
+    if nq > 2:
+        q[1] = 0.0                                                      # zero query
+    s0, i0 = _search(dev, bank, meta, q, k, fp32_scan=True)
+    s1, i1 = _search(dev, bank, meta, q, k)
+    assert torch.equal(i0, i1), f"{int((i0 != i1).any(1).sum())} of {nq} queries differ"
+    assert torch.equal(s0, s1)
+    sub = torch.arange(0, nq, max(1, nq // 6))[:6]
+    ri, rs = O.knn_exact_batch(bank, meta[:, 0], meta[:, 1], q[sub], k, NOW)
+    _, _, ok = topk_equivalent(i1[sub], s1[sub], ri, rs)
+    assert ok
+
+
+def test_two_stage_ties_and_overflow_fallback(dev):
+    """Thousands of identical rows: every one of them ties for the top score, the candidate lists
+    overflow, the library reports it and the wrapper re-runs the fp32 path: ties -> lower row."""
+    from aura_snn_rag_amd import ops
+    N, D = 20000, 64
+    g = torch.Generator().manual_seed(3)
+    bank = torch.randn(N, D, generator=g)
+    bank[5000:9000] = bank[5000]                                        # 4000 duplicates
+    meta = _meta(N, g)
+    q = (bank[5000] + 0.01 * torch.randn(3, D, generator=g)).contiguous()
+    s, i = _search(dev, bank, meta, q, 40)
+    assert i[0].tolist() == list(range(5000, 5040)) and i[2].tolist() == list(range(5000, 5040))
+    s0, i0 = _search(dev, bank, meta, q, 40, fp32_scan=True)
+    assert torch.equal(i, i0) and torch.equal(s, s0)
+    # the flag itself: without the wrapper's retry the overflow is reported, not hidden
+    _search(dev, bank, meta, q, 40, check_overflow=False)
+    assert int(ops._ovf_flags[torch.device(dev)].item()) == 1
+    # moderate duplication (fits the lists): exact without any fallback
+    bank2 = torch.randn(N, D, generator=g)
+    bank2[100:160] = bank2[100]
+    q2 = (bank2[100] + 0.01 * torch.randn(2, D, generator=g)).contiguous()
+    s2, i2 = _search(dev, bank2, meta, q2, 20, check_overflow=False)
+    assert int(ops._ovf_flags[torch.device(dev)].item()) == 0
+    assert i2[0].tolist() == list(range(100, 120))
