@@ -1653,7 +1653,7 @@ inline int run_coarse_pass(const float* bank, const float* inv_norm, const float
     c.dbg = cs_dbg;
     c.N = N; c.D = D; c.nq = nqb;
     c.thr = w.thr; c.cnt = w.cnt; c.cand_scores = w.cand_scores; c.cand_idx = w.cand_idx;
-    c.cap = w.cap; c.overflow = overflow_out;
+    c.cap = w.cap;
     const int cus = device_cu_count();
 
     c.n_tiles = G; c.tile_step = tile_step; c.n_sample = (int)n_sample;

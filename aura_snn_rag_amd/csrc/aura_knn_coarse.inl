@@ -43,7 +43,8 @@ constexpr int CS_QB = 4;                 // 16-query MFMA column blocks per wave
 constexpr int CS_ROWS = 16;              // bank rows per tile
 constexpr int CS_SLOTS = 3;
 constexpr int CS_AUX_BYTES = 1024;       // per slot: row constants (64 lanes x 16 B, first 16 used)
-constexpr int CS_BUF = 832;              // candidate entries buffered per workgroup
+constexpr int CS_BUF = 1024;             // candidate entries buffered per workgroup (two halves of 512)
+constexpr int CS_FLUSH_MIN = 128;        // a stable half is written out once it holds this many
 constexpr int CS_MODE_SAMPLE = 0, CS_MODE_FILTER = 1;
 constexpr int64_t COARSE_MIN_ROWS = 8192;
 constexpr int COARSE_MAX_K = 256;
@@ -69,7 +70,6 @@ struct CoarseArgs {
     float* cand_scores;      // [nq][cap]: U
     int32_t* cand_idx;
     int cap;
-    int32_t* overflow;       // set to 1 when a workgroup's candidate buffer overran (results invalid)
     int dbg;                 // AURA_CS_DBG timing ablations (results invalid when non-zero)
 };
 
@@ -87,7 +87,7 @@ __device__ __forceinline__ void glds4(const float* g, char* lds_wave_base) {
 // the 384 registers of query fragments are pinned by hand: the first CS_QA fragments live in
 // AGPRs (the hardware reads srcB from either file), the rest in VGPRs.  Hazards the compiler
 // would cover for its own MFMAs are covered by the s_nop statements around the groups.
-constexpr int CS_QA = 58;   // fragments (4 registers each) kept in AGPRs, next to the 16 accumulators
+constexpr int CS_QA = 60;   // fragments (4 registers each) kept in AGPRs, next to the 16 accumulators
 // LDS accesses of the steady-state loop that are NOT the MFMA fragments go through inline asm:
 // hipcc puts "s_waitcnt vmcnt(0)" in front of an ordinary LDS access it cannot separate from an
 // outstanding LDS-DMA (global_load_lds) -- which would drain the two-tile prefetch every tile.
@@ -99,6 +99,26 @@ __device__ __forceinline__ void lds_read4x16(uint32_t addr, float4& r0, float4& 
                  "ds_read_b128 %2, %4 offset:32\n\tds_read_b128 %3, %4 offset:48\n\t"
                  "s_waitcnt lgkmcnt(0)"
                  : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3) : "v"(addr) : "memory");
+}
+__device__ __forceinline__ void lds_read4x16_nowait(uint32_t addr, f32x4v& r0, f32x4v& r1, f32x4v& r2, f32x4v& r3) {
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\t"
+                 "ds_read_b128 %2, %4 offset:32\n\tds_read_b128 %3, %4 offset:48"
+                 : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3) : "v"(addr) : "memory");
+}
+__device__ __forceinline__ void lds_wait4(f32x4v& r0, f32x4v& r1, f32x4v& r2, f32x4v& r3) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3)::"memory");
+}
+__device__ __forceinline__ void lds_write_i32(uint32_t addr, int v) {
+    asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void lds_read3(uint32_t addr, uint32_t& a0, uint32_t& a1, uint32_t& a2) {
+    asm volatile("ds_read_b32 %0, %3\n\tds_read_b32 %1, %3 offset:4\n\tds_read_b32 %2, %3 offset:8\n\t"
+                 "s_waitcnt lgkmcnt(0)" : "=&v"(a0), "=&v"(a1), "=&v"(a2) : "v"(addr) : "memory");
+}
+// returning global atomic add whose result is NOT waited for here (the caller counts vmcnt itself:
+// an ordinary atomicAdd would make hipcc wait vmcnt(0) and drain the LDS-DMA prefetch)
+__device__ __forceinline__ void gatomic_inc_nowait(int32_t* p, int& ret) {
+    asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=&v"(ret) : "v"(p), "v"(1) : "memory");
 }
 __device__ __forceinline__ int lds_add_rtn(uint32_t addr, int v) {
     int r;
@@ -140,7 +160,7 @@ __device__ __forceinline__ void mfma_bf16_q(f32x4v& acc, const bf16x8v& af, cons
 //     ([256-query block][wave][16-query block][k-step][lane][8], zero padded): a fragment is one
 //     coalesced 1-KiB wave load;
 //   blocks [qblocks, ...): 256 rows each: the row's share of the combined score folded into
-//     U = t * A + B_up,  L = t * A + B_lo   with t = (q . row) / ||q||:
+//     U = t * A + B_up,  L = t * A + B_lo   with t = (q / ||q||) . row:
 //     A = 0.5 strength / ||row||,  B = 0.2 exp(-(now - ts)/3600) strength +- E_row.
 //     (Association differs from the exact epilogue by a few ulp: covered by the 1e-5 in E_cos.)
 __global__ __launch_bounds__(256) void coarse_prep_kernel(const float* __restrict__ x, int64_t nq,
@@ -169,24 +189,8 @@ __global__ __launch_bounds__(256) void coarse_prep_kernel(const float* __restric
     const int64_t qblk = q >> 8;
     const int wq = (int)(q >> 6) & 3, b = (int)(q >> 4) & 3, lr = (int)q & 15;
     uint16_t* const base = qhat + ((((qblk * 4 + wq) * 4 + b) * KS) * 64 + lr) * 8;
-    float s = 0.0f;
-    for (int c = lane; c < KS * 4; c += 64) {             // chunk c: k = 8c .. 8c+7 = k-step c/4, lg c%4
-        f32x8v v;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = 0.0f;
-        const int64_t k0 = 8 * (int64_t)c;
-        if (q < nq && k0 < D) {
-            const float4 u = *reinterpret_cast<const float4*>(x + q * D + k0);      // D % 4 == 0
-            v[0] = u.x; v[1] = u.y; v[2] = u.z; v[3] = u.w;
-            if (k0 + 4 < D) {
-                const float4 w = *reinterpret_cast<const float4*>(x + q * D + k0 + 4);
-                v[4] = w.x; v[5] = w.y; v[6] = w.z; v[7] = w.w;
-            }
-        }
-        *reinterpret_cast<bf16x8v*>(base + ((int64_t)(c >> 2) * 64 + (c & 3) * 16) * 8) =
-            __builtin_convertvector(v, bf16x8v);
-    }
     // 1/||q|| with query_prep_kernel's arithmetic (the re-scored results must not depend on the path)
+    float s = 0.0f;
     if (q < nq)
         for (int64_t i = lane * 4; i < D; i += 256) {
             const float4 u = *reinterpret_cast<const float4*>(x + q * D + i);
@@ -194,7 +198,25 @@ __global__ __launch_bounds__(256) void coarse_prep_kernel(const float* __restric
         }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-    if (lane == 0 && q < nq) inv[q] = 1.0f / fmaxf(sqrtf(s), 1e-12f);
+    const float iqv = 1.0f / fmaxf(sqrtf(s), 1e-12f);
+    if (lane == 0 && q < nq) inv[q] = iqv;
+    // fragments hold the NORMALISED query: the scan's accumulator is the cosine numerator / ||q||
+    for (int c = lane; c < KS * 4; c += 64) {             // chunk c: k = 8c .. 8c+7 = k-step c/4, lg c%4
+        f32x8v v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.0f;
+        const int64_t k0 = 8 * (int64_t)c;
+        if (q < nq && k0 < D) {
+            const float4 u = *reinterpret_cast<const float4*>(x + q * D + k0);      // D % 4 == 0
+            v[0] = u.x * iqv; v[1] = u.y * iqv; v[2] = u.z * iqv; v[3] = u.w * iqv;
+            if (k0 + 4 < D) {
+                const float4 w = *reinterpret_cast<const float4*>(x + q * D + k0 + 4);
+                v[4] = w.x * iqv; v[5] = w.y * iqv; v[6] = w.z * iqv; v[7] = w.w * iqv;
+            }
+        }
+        *reinterpret_cast<bf16x8v*>(base + ((int64_t)(c >> 2) * 64 + (c & 3) * 16) * 8) =
+            __builtin_convertvector(v, bf16x8v);
+    }
 }
 
 // T[q] = k-th largest of the G group maxima: one wave per query, PER keys per lane in registers;
@@ -236,8 +258,8 @@ __global__ __launch_bounds__(CS_THREADS) void coarse_scan_kernel(const CoarseArg
     constexpr int NP = KS / 2;                             // bank pieces per wave and tile
     constexpr int GL = NP + 1;                             // global_load_lds per wave and tile
     extern __shared__ __attribute__((aligned(16))) char csmem[];
-    uint32_t* const s_buf = reinterpret_cast<uint32_t*>(csmem + CS_SLOTS * SLOT_BYTES);  // [CS_BUF][3]
-    __shared__ int s_nbuf;
+    uint32_t* const s_buf = reinterpret_cast<uint32_t*>(csmem + CS_SLOTS * SLOT_BYTES);  // [2][CS_BUF/2][3]
+    __shared__ int s_nb[2];
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -248,56 +270,74 @@ __global__ __launch_bounds__(CS_THREADS) void coarse_scan_kernel(const CoarseArg
     const int64_t total = a.n_tiles * nqblk;
     const int64_t lo = total * (int64_t)blockIdx.x / gridDim.x;
     const int64_t hi = total * ((int64_t)blockIdx.x + 1) / gridDim.x;
-    if (tid == 0) s_nbuf = 0;
+    if (tid < 2) s_nb[tid] = 0;
+    __syncthreads();
 
     // reader offsets inside a k-step block: chunks 2g and 2g+1 of row lr, XOR-swizzled
     const int sw = (lr >> 1) & 7;
     const int off0 = (8 * lr + ((2 * lg) ^ sw)) * 16;
     const int off1 = (8 * lr + ((2 * lg + 1) ^ sw)) * 16;
-    // loader roles: piece m = wave + 4 i -> k-step m>>1, row half m&1; lane -> row rho, 16-B chunk c
-    // (the image is swizzled by choosing WHICH chunk a lane fetches: LDS-DMA writes lane-linear).
-    // Columns beyond D re-read the row's last 16 bytes: finite data times the queries' zero padding.
-    uint32_t voff[NP];                                     // byte offset from the tile's first row
-#pragma unroll
-    for (int i = 0; i < NP; ++i) {
-        const int m = wave + 4 * i;
-        const int s = m >> 1, half = m & 1;
-        const uint32_t rho = 8 * half + (lane >> 3);
-        const uint32_t cch = (lane & 7) ^ ((rho >> 1) & 7);
-        uint32_t kf = 32 * s + 4 * cch;
-        if (kf >= D) kf = D - 4;
-        voff[i] = (rho * D + kf) * 4u;
-    }
+    // loader roles: piece m = wave + 4 i -> k-step m>>1 = (wave>>1) + 2 i, row half m&1 = wave&1 (the
+    // same for all of a wave's pieces); lane -> row rho = 8 half + lane/8, 16-byte chunk cch of the
+    // 128-byte line (the image is swizzled by choosing WHICH chunk a lane fetches: LDS-DMA writes
+    // lane-linear).  A wave's pieces are 256 bytes apart in the row, so one offset register serves
+    // them all.  Columns beyond D re-read the row's last 16 bytes: finite data times the queries'
+    // zero padding (ragged D only; clamped per piece).
+    const uint32_t ld_rho = 8 * (wave & 1) + (lane >> 3);
+    const uint32_t ld_cch = (lane & 7) ^ ((ld_rho >> 1) & 7);
+    const uint32_t ld_kf0 = 32 * (wave >> 1) + 4 * ld_cch;          // floats; piece i: + 64 i
+    const uint32_t voff0 = (ld_rho * D + ld_kf0) * 4u;              // bytes from the tile's first row
+    const bool full_k = D == (uint32_t)(KS * 32);
 
     auto tile_row0 = [&](int64_t j) -> int64_t {
         if (MODE == CS_MODE_SAMPLE) return ((j >> 3) * a.tile_step) * 128 + (j & 7) * 16;
         return j * 16;
     };
     auto issue = [&](int64_t j, int slot) {
-        char* const sb = csmem + slot * SLOT_BYTES;
+        char* const sb = csmem + slot * SLOT_BYTES + (wave & 1) * 1024 + (wave >> 1) * 2048;
         const int64_t r0 = tile_row0(j);
-        const char* const base = reinterpret_cast<const char*>(a.bank + r0 * (int64_t)D);
-        if (r0 + CS_ROWS <= a.N) {
+        const char* base = reinterpret_cast<const char*>(a.bank + r0 * (int64_t)D);
+        if (r0 + CS_ROWS > a.N) {                          // last, partial tile: clamp the row
+            const uint32_t last = (uint32_t)(a.N - 1 - r0);
+            if (ld_rho > last) base -= (int64_t)(ld_rho - last) * D * 4;
+        }
+        if (full_k) {
 #pragma unroll
+            for (int i = 0; i < NP; ++i)
+                glds16(reinterpret_cast<const float*>(base + voff0 + 256 * i), sb + i * 4096);
+        } else {
+            uint32_t kf0 = ld_kf0;
+            asm volatile("" : "+v"(kf0));                  // recompute per call: hoisting these 12
+#pragma unroll                                             // addresses out of the tile loop spills
             for (int i = 0; i < NP; ++i) {
-                const int m = wave + 4 * i;
-                glds16(reinterpret_cast<const float*>(base + voff[i]), sb + (m >> 1) * 2048 + (m & 1) * 1024);
-            }
-        } else {                                           // last, partial tile: clamp the row
-#pragma unroll
-            for (int i = 0; i < NP; ++i) {
-                const int m = wave + 4 * i;
-                const uint32_t rho = 8 * (m & 1) + (lane >> 3);
-                const uint32_t last = (uint32_t)(a.N - 1 - r0);
-                const uint32_t o = rho <= last ? voff[i] : voff[i] - (rho - last) * D * 4u;
-                glds16(reinterpret_cast<const float*>(base + o), sb + (m >> 1) * 2048 + (m & 1) * 1024);
+                uint32_t kf = kf0 + 64 * i;
+                if (kf >= D) kf = D - 4;
+                glds16(reinterpret_cast<const float*>(base + (ld_rho * D + kf) * 4u), sb + i * 4096);
             }
         }
         {   // row constants (every wave issues the same piece: uniform vmcnt, same bytes)
             int64_t row = r0 + (lane & 15);
             if (row >= a.N) row = a.N - 1;
-            glds16(reinterpret_cast<const float*>(a.rowc + row), sb + TILE_BYTES);
+            glds16(reinterpret_cast<const float*>(a.rowc + row), csmem + slot * SLOT_BYTES + TILE_BYTES);
         }
+    };
+
+    // candidate buffer: two halves; tile t appends to half t&1, so the other half is stable during
+    // tile t and can be inspected / flushed without any extra barrier
+    constexpr int HALF = CS_BUF / 2;
+    const uint32_t nb_addr = lds_addr(s_nb), buf_addr = lds_addr(s_buf);
+    auto flush_half = [&](int h, int nb) {                 // all threads; nb uniform
+        const int n = nb < HALF ? nb : HALF;
+        for (int i = tid; i < n; i += CS_THREADS) {
+            const uint32_t* e = s_buf + (h * HALF + i) * 3;
+            const int q = (int)e[0];
+            const int p = atomicAdd(a.cnt + (int64_t)q * CNT_STRIDE, 1);
+            if (p < a.cap) {
+                a.cand_scores[(int64_t)q * a.cap + p] = __uint_as_float(e[2]);
+                a.cand_idx[(int64_t)q * a.cap + p] = (int32_t)e[1];
+            }
+        }
+        if (tid == 0) s_nb[h] = 0;                           // (entries beyond HALF went out directly)
     };
 
     int64_t c = lo;
@@ -307,16 +347,20 @@ __global__ __launch_bounds__(CS_THREADS) void coarse_scan_kernel(const CoarseArg
         c += seg;
         const int qoff = (int)qblk * 256 + wave * 64;      // this wave's first query
 
-        // ---- stationary operand: 64 queries of this wave as bf16 B-fragments ----
-        // one 16-byte load per fragment, all in flight at once, landing in their final registers
+        // the first two tiles start streaming before anything else
+        issue(j0, 0);
+        if (seg > 1) issue(j0 + 1, 1);
+
+        // ---- stationary operand: 64 (normalised) queries of this wave as bf16 B-fragments ----
+        // one coalesced 16-byte load per lane and fragment, all in flight at once, landing in
+        // their final registers
         bf16x8v qf[CS_QB][KS];
-        float iq[CS_QB], thrf[CS_QB];
+        float thrf[CS_QB];
 #pragma unroll
         for (int b = 0; b < CS_QB; ++b) {
             const int q = qoff + 16 * b + lr;
-            const bool vq = q < a.nq;
-            iq[b] = vq ? a.inv_q[q] : 0.0f;
-            thrf[b] = (MODE == CS_MODE_FILTER && vq) ? ord_unkey(a.thr[q]) : INFINITY;
+            const uint32_t key = a.thr[q < a.nq ? q : a.nq - 1];          // unconditional load
+            thrf[b] = (MODE == CS_MODE_FILTER && q < a.nq) ? ord_unkey(key) : INFINITY;
             const uint16_t* qp = a.qhat + ((((qblk * 4 + wave) * 4 + b) * KS) * 64 + lane) * 8;
 #pragma unroll
             for (int s = 0; s < KS; ++s)
@@ -331,17 +375,33 @@ __global__ __launch_bounds__(CS_THREADS) void coarse_scan_kernel(const CoarseArg
                 else asm volatile("" : "=v"(qf[b][s]) : "0"(qf[b][s]));
             }
         }
-        // all ordinary loads above are consumed; from here to the flush only LDS-DMA is in flight
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // ordinary loads are all consumed here; until the span ends only LDS-DMA is in flight
+        // (plus the rare flush)
 
-        issue(j0, 0);
-        if (seg > 1) issue(j0 + 1, 1);
         int slot = 0;
         for (int64_t t = 0; t < seg; ++t) {
-            if (t + 1 < seg) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GL) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (t + 1 < seg) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(GL) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            const int par = (int)(t & 1);
+            // The half tile t-1 appended to is stable during this tile.  Once it holds enough entries
+            // it is written out in two steps that never stall the stream: the slot reservations
+            // (returning atomics) are issued here, ahead of the next tile's LDS-DMA, and consumed after
+            // the MFMA loop with a counted wait.
+            int fl_n = 0, fl_pos0 = 0, fl_pos1 = 0;
+            if (MODE == CS_MODE_FILTER) {
+                const int nbo = __builtin_amdgcn_readfirstlane(lds_read_i32(nb_addr + (par ^ 1) * 4));
+                if (nbo >= CS_FLUSH_MIN) {
+                    fl_n = nbo < HALF ? nbo : HALF;
+                    const uint32_t eb = buf_addr + (par ^ 1) * (HALF * 12);
+                    if (tid < fl_n)
+                        gatomic_inc_nowait(a.cnt + (int64_t)lds_read_i32(eb + tid * 12) * CNT_STRIDE, fl_pos0);
+                    if (tid + CS_THREADS < fl_n)
+                        gatomic_inc_nowait(a.cnt + (int64_t)lds_read_i32(eb + (tid + CS_THREADS) * 12) * CNT_STRIDE,
+                                           fl_pos1);
+                }
+            }
             if (t + 2 < seg && !(a.dbg & 4)) issue(j0 + t + 2, slot == 0 ? 2 : slot - 1);
 
             const char* const sb = csmem + slot * SLOT_BYTES;
@@ -350,6 +410,7 @@ __global__ __launch_bounds__(CS_THREADS) void coarse_scan_kernel(const CoarseArg
             for (int b = 0; b < CS_QB; ++b)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[b][e] = 0.0f;
+            f32x4v rcv[4];                                   // constants of rows 4 lg .. 4 lg + 3
             // fragment reads run two k-steps ahead of the MFMAs (one wave per SIMD: nothing else
             // hides the LDS latency)
             f32x4v xr[3][2];
@@ -380,32 +441,52 @@ __global__ __launch_bounds__(CS_THREADS) void coarse_scan_kernel(const CoarseArg
                         else mfma_bf16_q<false, false>(acc[b], af, qf[b][s]);
                     }
                 }
+                // the epilogue's row constants are fetched behind the last two k-steps
+                if (s == (KS >= 3 ? KS - 3 : 0))
+                    lds_read4x16_nowait(lds_addr(sb + TILE_BYTES) + lg * 64, rcv[0], rcv[1], rcv[2], rcv[3]);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            } else {
+                lds_read4x16_nowait(lds_addr(sb + TILE_BYTES) + lg * 64, rcv[0], rcv[1], rcv[2], rcv[3]);
             }
+            lds_wait4(rcv[0], rcv[1], rcv[2], rcv[3]);
             __builtin_amdgcn_sched_barrier(0);
+            if (MODE == CS_MODE_FILTER && fl_n > 0) {       // second step of the write-out (uniform)
+                if (t + 2 < seg) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GL) : "memory");   // reservations are older
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const uint32_t eb = buf_addr + (par ^ 1) * (HALF * 12);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int i = tid + u * CS_THREADS;
+                    const int pos = u == 0 ? fl_pos0 : fl_pos1;
+                    if (i < fl_n && pos < a.cap) {
+                        uint32_t eq, er, eu;
+                        lds_read3(eb + i * 12, eq, er, eu);
+                        a.cand_scores[(int64_t)eq * a.cap + pos] = __uint_as_float(eu);
+                        a.cand_idx[(int64_t)eq * a.cap + pos] = (int32_t)er;
+                    }
+                }
+                if (tid == 0) lds_write_i32(nb_addr + (par ^ 1) * 4, 0);   // seen by all after the next barrier
+            }
 
             // ---- epilogue: rows 4 lg + e of the tile, queries qoff + 16 b + lr ----
             const int64_t r0 = tile_row0(j0 + t);
+            const int rows_left = (int)((a.N - r0) < CS_ROWS ? (a.N - r0) : CS_ROWS);
             float gm[CS_QB];
             unsigned bits = 0u;
             if (!(a.dbg & 2)) {
 #pragma unroll
             for (int b = 0; b < CS_QB; ++b) gm[b] = -INFINITY;
-            float4 rcv[4];                                   // constants of rows 4 lg .. 4 lg + 3
-            lds_read4x16(lds_addr(sb + TILE_BYTES) + lg * 64, rcv[0], rcv[1], rcv[2], rcv[3]);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int rr = 4 * lg + e;
-                const float4 rc = rcv[e];
-                const bool vrow = r0 + rr < a.N;
+                const f32x4v rc = rcv[e];
+                const bool vrow = 4 * lg + e < rows_left;
 #pragma unroll
                 for (int b = 0; b < CS_QB; ++b) {
-                    const float tq = acc[b][e] * iq[b];
                     if (MODE == CS_MODE_SAMPLE) {
-                        gm[b] = fmaxf(gm[b], vrow ? tq * rc.x + rc.z : -INFINITY);
+                        gm[b] = fmaxf(gm[b], vrow ? acc[b][e] * rc[0] + rc[2] : -INFINITY);
                     } else {
-                        const float up = tq * rc.x + rc.y;
+                        const float up = acc[b][e] * rc[0] + rc[1];
                         acc[b][e] = up;
                         bits |= (vrow && up >= thrf[b]) ? (1u << (b * 4 + e)) : 0u;   // thrf = +inf: q >= nq
                     }
@@ -421,52 +502,44 @@ __global__ __launch_bounds__(CS_THREADS) void coarse_scan_kernel(const CoarseArg
                     const int q = qoff + 16 * b + lr;
                     if (lg == 0 && q < a.nq) a.gmax[(int64_t)q * a.gmax_ld + (j0 + t)] = mx;
                 }
-            } else if (bits != 0u) {
-                int p = lds_add_rtn(lds_addr(&s_nbuf), __popc(bits));
-                const uint32_t bufa = lds_addr(s_buf);
+            } else if (bits != 0u && !(a.dbg & 32)) {
+                int p = lds_add_rtn(nb_addr + par * 4, __popc(bits));
+                const uint32_t bufa = buf_addr + par * (HALF * 12);
 #pragma unroll
                 for (int b = 0; b < CS_QB; ++b) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         if ((bits >> (b * 4 + e)) & 1u) {
-                            if (p < CS_BUF)
-                                lds_write3(bufa + p * 12, (uint32_t)(qoff + 16 * b + lr),
-                                           (uint32_t)(r0 + 4 * lg + e), __float_as_uint(acc[b][e]));
+                            const int q = qoff + 16 * b + lr;
+                            if (p < HALF) {
+                                lds_write3(bufa + p * 12, (uint32_t)q, (uint32_t)(r0 + 4 * lg + e),
+                                           __float_as_uint(acc[b][e]));
+                            } else {
+                                // burst beyond the buffer (e.g. a run of fresh rows that every query
+                                // wants): straight to the query's list; slow (drains the prefetch) but exact
+                                const int gp = atomicAdd(a.cnt + (int64_t)q * CNT_STRIDE, 1);
+                                if (gp < a.cap) {
+                                    a.cand_scores[(int64_t)q * a.cap + gp] = acc[b][e];
+                                    a.cand_idx[(int64_t)q * a.cap + gp] = (int32_t)(r0 + 4 * lg + e);
+                                }
+                            }
                             ++p;
                         }
                     }
-                }
-            }
-            if (MODE == CS_MODE_FILTER && ((t & 1) == 1 || t + 1 == seg)) {
-                // uniform decision point: the count is read between two barriers
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-                const int nb = __builtin_amdgcn_readfirstlane(lds_read_i32(lds_addr(&s_nbuf)));
-                if (t + 1 == seg || nb > CS_BUF / 2) {
-                    // flush (rare inside a span; its ordinary atomics drain the LDS-DMA ring, after
-                    // which the counted waits above are simply already satisfied)
-                    const int n = nb < CS_BUF ? nb : CS_BUF;
-                    for (int i = tid; i < n; i += CS_THREADS) {
-                        const int q = (int)s_buf[i * 3];
-                        const int p = atomicAdd(a.cnt + (int64_t)q * CNT_STRIDE, 1);
-                        if (p < a.cap) {
-                            a.cand_scores[(int64_t)q * a.cap + p] = __uint_as_float(s_buf[i * 3 + 2]);
-                            a.cand_idx[(int64_t)q * a.cap + p] = (int32_t)s_buf[i * 3 + 1];
-                        }
-                    }
-                    if (nb > CS_BUF && tid == 0 && a.overflow) *a.overflow = 1;   // entries were dropped
-                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();                  // every wave has read nb / the entries
-                    if (tid == 0) s_nbuf = 0;
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();                  // ... and sees the reset before it appends
                 }
             }
             slot = slot == 2 ? 0 : slot + 1;
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        if (MODE == CS_MODE_FILTER) {                       // span end: both halves go out
+            const int n0 = __builtin_amdgcn_readfirstlane(lds_read_i32(nb_addr));
+            const int n1 = __builtin_amdgcn_readfirstlane(lds_read_i32(nb_addr + 4));
+            if (n0 > 0) flush_half(0, n0);
+            if (n1 > 0) flush_half(1, n1);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
     }
 }
 
@@ -511,7 +584,8 @@ __global__ __launch_bounds__(RF_THREADS) void coarse_refine_kernel(const RefineA
     int n = a.cnt[(int64_t)q * CNT_STRIDE];
     bool ovf = false;
     const int capn = a.cap < RF_CAP ? a.cap : RF_CAP;
-    if (n > capn) { ovf = true; n = capn; }
+    int ovf_bits = 0;
+    if (n > capn) { ovf = true; ovf_bits |= 4; n = capn; }
 
     for (int i = tid; i < n; i += RF_THREADS) {
         const float u = a.cand_scores[(int64_t)q * a.cap + i];
@@ -571,8 +645,8 @@ __global__ __launch_bounds__(RF_THREADS) void coarse_refine_kernel(const RefineA
     }
     __syncthreads();
     int S = s_ns;
-    if (S > RF_SURV) { ovf = true; S = RF_SURV; }
-    if (ovf && tid == 0 && a.overflow) *a.overflow = 1;
+    if (S > RF_SURV) { ovf = true; ovf_bits |= 8; S = RF_SURV; }
+    if (ovf && tid == 0 && a.overflow) atomicOr(a.overflow, ovf_bits);   // which list overflowed
     __syncthreads();     // candidate arrays are dead from here: rsmem is reused below
 
     // ---- exact re-scoring: wave w takes survivors w*16 .. w*16+15 of each round of 128 ----

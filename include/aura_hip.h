@@ -129,8 +129,9 @@ int aura_knn_search(const float* bank, const float* inv_norm, const float* meta,
  * src/core/hippocampal.py:259-270 (a query left without candidates returns idx -1 everywhere and
  * the caller falls back to the full scan, :269-270); flags (AURA_KNN_FORCE_DENSE scores every row densely instead
  * of using the sampled-threshold filter; same results, used by tests) and overflow_out (device
- * int32, set to 1 if a candidate list overflowed -- the caller must then re-run with
- * AURA_KNN_FORCE_DENSE; may be NULL). */
+ * int32, reset by every call and set non-zero if a candidate list overflowed -- bit 0: filter
+ * list of the fp32 scan, bit 2 / bit 3: candidate / survivor list of the two-stage path -- the
+ * caller must then re-run with AURA_KNN_FORCE_DENSE; may be NULL). */
 #define AURA_KNN_FORCE_DENSE 1
 /* AURA_KNN_FP32_SCAN: score every row on the fp32 matrix pipe.  Without it, large banks
  * (>= 8192 rows, D <= 768, D % 4 == 0, no location term / centroid mask, k <= 256) are first

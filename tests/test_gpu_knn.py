@@ -425,7 +425,7 @@ def test_two_stage_ties_and_overflow_fallback(dev):
     assert torch.equal(i, i0) and torch.equal(s, s0)
     # the flag itself: without the wrapper's retry the overflow is reported, not hidden
     _search(dev, bank, meta, q, 40, check_overflow=False)
-    assert int(ops._ovf_flags[torch.device(dev)].item()) == 1
+    assert int(ops._ovf_flags[torch.device(dev)].item()) != 0     # bit 8: more survivors than the refine kernel holds
     # moderate duplication (fits the lists): exact without any fallback
     bank2 = torch.randn(N, D, generator=g)
     bank2[100:160] = bank2[100]
