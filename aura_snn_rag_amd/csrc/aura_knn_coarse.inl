@@ -347,25 +347,35 @@ __global__ __launch_bounds__(CS_THREADS) void coarse_scan_kernel(const CoarseArg
         c += seg;
         const int qoff = (int)qblk * 256 + wave * 64;      // this wave's first query
 
-        // the first two tiles start streaming before anything else
-        issue(j0, 0);
-        if (seg > 1) issue(j0 + 1, 1);
-
         // ---- stationary operand: 64 (normalised) queries of this wave as bf16 B-fragments ----
         // one coalesced 16-byte load per lane and fragment, all in flight at once, landing in
         // their final registers
         bf16x8v qf[CS_QB][KS];
         float thrf[CS_QB];
+        if (MODE == CS_MODE_FILTER) {                       // thresholds first: their wait must not
+            uint32_t key[CS_QB];                              // sit between the fragment loads
+#pragma unroll
+            for (int b = 0; b < CS_QB; ++b) {
+                const int q = qoff + 16 * b + lr;
+                key[b] = a.thr[q < a.nq ? q : a.nq - 1];
+            }
+#pragma unroll
+            for (int b = 0; b < CS_QB; ++b) thrf[b] = qoff + 16 * b + lr < a.nq ? ord_unkey(key[b]) : INFINITY;
+        } else {
+#pragma unroll
+            for (int b = 0; b < CS_QB; ++b) thrf[b] = INFINITY;
+        }
 #pragma unroll
         for (int b = 0; b < CS_QB; ++b) {
-            const int q = qoff + 16 * b + lr;
-            const uint32_t key = a.thr[q < a.nq ? q : a.nq - 1];          // unconditional load
-            thrf[b] = (MODE == CS_MODE_FILTER && q < a.nq) ? ord_unkey(key) : INFINITY;
             const uint16_t* qp = a.qhat + ((((qblk * 4 + wave) * 4 + b) * KS) * 64 + lane) * 8;
 #pragma unroll
             for (int s = 0; s < KS; ++s)
                 qf[b][s] = *reinterpret_cast<const bf16x8v*>(qp + (int64_t)s * 512);
         }
+        // the first two tiles start streaming while the fragments are still in flight: the single
+        // wait in front of the first pin below then covers fragments and tiles alike
+        issue(j0, 0);
+        if (seg > 1) issue(j0 + 1, 1);
 #pragma unroll
         for (int b = 0; b < CS_QB; ++b) {
 #pragma unroll
