@@ -63,7 +63,8 @@ class HippocampalFormation(nn.Module):
                  feature_dim: int = 768,
                  device: str = 'cuda',
                  use_centroid_index: bool = True,
-                 overflow: str = 'reference'):
+                 overflow: str = 'reference',
+                 bf16_shadow: bool = True):
         super().__init__()
         self.spatial_dims = spatial_dimensions
         self.device = torch.device(device if torch.cuda.is_available() else 'cpu')
@@ -91,6 +92,11 @@ class HippocampalFormation(nn.Module):
         # build-side: 1/max(||row||, 1e-12), refreshed by every write (not part of the state_dict)
         self.register_buffer('_inv_norm', torch.zeros(max_memories, device=dev), persistent=False)
         self._norms_valid_upto = 0
+        # build-side: bf16 copy of the rows for the exact recall's prefilter (half the bytes to
+        # stream; results unchanged).  Allocated on the first full-scan recall of >= 8192 rows.
+        self._use_shadow = bool(bf16_shadow) and feature_dim % 8 == 0 and feature_dim <= 768
+        self._shadow = None
+        self._shadow_valid_upto = 0
 
         self.episodic_memories: Dict[str, EpisodicMemory] = {}
         self.id_to_idx: Dict[str, int] = {}
@@ -121,7 +127,29 @@ class HippocampalFormation(nn.Module):
     # ------------------------------------------------------------------ plumbing
     def _invalidate_norms(self) -> None:
         self._norms_valid_upto = 0
+        self._shadow_valid_upto = 0
         self._lists = None
+
+    def _ensure_shadow(self):
+        """bf16 shadow of rows [0, memory_count), or None when it does not apply."""
+        if not self._use_shadow or self.memory_count < 8192 or not self.memory_features.is_cuda:
+            return None
+        if self._shadow is None or self._shadow.device != self.memory_features.device:
+            self._shadow = torch.empty(self.memory_features.shape, dtype=torch.bfloat16,
+                                       device=self.memory_features.device)
+            self._shadow_valid_upto = 0
+        if self._shadow_valid_upto < self.memory_count:
+            lo = self._shadow_valid_upto
+            ops.bank_shadow_update(self.memory_features, self._shadow, lo, self.memory_count - lo)
+            self._shadow_valid_upto = self.memory_count
+        return self._shadow
+
+    def _shadow_after_write(self, slot_t: torch.Tensor, lo: int, hi: int) -> None:
+        """Keep the shadow current for rows just written (only the part it already covers)."""
+        if self._shadow is None or self._shadow_valid_upto <= lo:
+            return                                  # those rows get converted by _ensure_shadow
+        ops.bank_shadow_update(self.memory_features, self._shadow, slots=slot_t)
+        self._shadow_valid_upto = max(self._shadow_valid_upto, min(hi + 1, self.memory_count))
 
     def _ensure_lists(self):
         """Inverted lists for the IVF recall: row ids of [0, memory_count) sorted by centroid id
@@ -155,8 +183,10 @@ class HippocampalFormation(nn.Module):
             self._norms_valid_upto = self.memory_count
 
     def refresh_norms(self) -> None:
-        """Recompute the cached row norms (call after writing ``memory_features`` directly)."""
+        """Recompute the cached row norms and drop the bf16 shadow (call after writing
+        ``memory_features`` directly)."""
         self._norms_valid_upto = 0
+        self._shadow_valid_upto = 0
         if self.memory_count:
             self._ensure_norms()
 
@@ -234,6 +264,7 @@ class HippocampalFormation(nn.Module):
         lo, hi = min(slots), max(slots)
         if self._norms_valid_upto >= lo:      # the kernel refreshed 1/||row|| of the written slots
             self._norms_valid_upto = max(self._norms_valid_upto, hi + 1)
+        self._shadow_after_write(slot_t, lo, hi)
         stamp = time.time()
         for mid, slot in zip(ids, slots):
             self.episodic_memories[mid] = EpisodicMemory(memory_id=mid, feature_idx=slot, timestamp=stamp)
@@ -272,6 +303,7 @@ class HippocampalFormation(nn.Module):
         self._lists = None
         if self._norms_valid_upto >= s0:
             self._norms_valid_upto = s0 + n
+        self._shadow_after_write(slot_t, s0, s0 + n - 1)
         self._implicit_ids.append((s0, s0 + n, id_prefix, first_index))
         if rebuild and self.use_centroid_index and self.memory_count > self.centroids_k:
             self.rebuild_centroids()
@@ -336,7 +368,9 @@ class HippocampalFormation(nn.Module):
         kw = dict(count=self.memory_count, loc=self.memory_locations if q_loc is not None else None,
                   q_loc=q_loc, check_overflow=check_overflow)
         if not cand:
-            return ops.knn_search(self.memory_features, self._inv_norm, self.memory_metadata, q, kk, now, **kw)
+            shadow = self._ensure_shadow() if q_loc is None else None
+            return ops.knn_search(self.memory_features, self._inv_norm, self.memory_metadata, q, kk, now,
+                                  shadow=shadow, **kw)
         nprobe = min(8, self.centroids_k)
         scores = rows = None
         if q_loc is None and self.centroids.shape[0] == 256:

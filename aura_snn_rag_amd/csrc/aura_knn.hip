@@ -1619,8 +1619,8 @@ inline int dispatch_scan(const ScanArgs& a, int mode, int64_t ntiles_grid, hipSt
 
 // Two-stage recall of one query pass (see aura_knn_coarse.inl).  Returns AURA_OK after queuing
 // sample scan -> threshold -> filter scan -> refine; the caller skips the fp32 pipeline.
-inline int run_coarse_pass(const float* bank, const float* inv_norm, const float* meta,
-                           const float* qptr, float now, int64_t N, int64_t D, int nqb, int k,
+inline int run_coarse_pass(const float* bank, const uint16_t* bank16, const float* inv_norm,
+                           const float* meta, const float* qptr, float now, int64_t N, int64_t D, int nqb, int k,
                            int32_t idx_base, float* out_scores, int32_t* out_idx,
                            const Workspace& w, int32_t* overflow_out, bool reset_flag, hipStream_t s) {
     int rc;
@@ -1649,6 +1649,8 @@ inline int run_coarse_pass(const float* bank, const float* inv_norm, const float
     if ((rc = check_launch())) return rc;
     CoarseArgs c{};
     c.bank = bank; c.rowc = w.rowc; c.qhat = w.qhat; c.inv_q = w.inv_q;
+    // the shadow is only usable when its rows are 16-byte aligned
+    c.bank16 = (bank16 && (D & 7) == 0 && (reinterpret_cast<uintptr_t>(bank16) & 15) == 0) ? bank16 : nullptr;
     static const int cs_dbg = getenv("AURA_CS_DBG") ? atoi(getenv("AURA_CS_DBG")) : 0;
     c.dbg = cs_dbg;
     c.N = N; c.D = D; c.nq = nqb;
@@ -1679,7 +1681,7 @@ inline int run_coarse_pass(const float* bank, const float* inv_norm, const float
     const bool prof = g_prof.on && g_prof.used < g_prof.cap;
     if (prof) {
         (void)hipEventRecord(g_prof.start[g_prof.used], s);
-        g_prof.rows = N; g_prof.nq = nqb; g_prof.kind = 1;
+        g_prof.rows = N; g_prof.nq = nqb; g_prof.kind = c.bank16 ? 2 : 1;
     }
     {
         const int64_t items = c.n_tiles * ((nqb + 255) / 256);
@@ -1766,11 +1768,12 @@ int64_t aura_knn_workspace_bytes(int64_t N, int64_t nq, int k) {
     return carve(nullptr, N, nq, k).bytes;
 }
 
-int aura_knn_search_ex(const float* bank, const float* inv_norm, const float* meta, const float* loc,
-                       int spatial_dims, const float* queries, const float* q_loc, float now,
-                       int64_t N, int64_t D, int64_t nq, int k, int32_t idx_base, float* out_scores,
-                       int32_t* out_idx, void* workspace, int64_t workspace_bytes, int flags,
-                       int32_t* overflow_out, const float* centroids, int nprobe, void* stream) {
+static int knn_search_impl(const float* bank, const uint16_t* bank_bf16, const float* inv_norm,
+                           const float* meta, const float* loc,
+                           int spatial_dims, const float* queries, const float* q_loc, float now,
+                           int64_t N, int64_t D, int64_t nq, int k, int32_t idx_base, float* out_scores,
+                           int32_t* out_idx, void* workspace, int64_t workspace_bytes, int flags,
+                           int32_t* overflow_out, const float* centroids, int nprobe, void* stream) {
     if (N < 0 || D <= 0 || nq < 0 || k <= 0 || k > SEL_MAX_K || k > N) return AURA_E_INVAL;
     if (centroids && (nprobe <= 0 || nprobe > 256)) return AURA_E_INVAL;
     if (flags & ~(AURA_KNN_FORCE_DENSE | AURA_KNN_FP32_SCAN)) return AURA_E_INVAL;
@@ -1799,7 +1802,7 @@ int aura_knn_search_ex(const float* bank, const float* inv_norm, const float* me
         }
 
         if (coarse_eligible(bank, qptr, q_loc, centroids, N, D, k, flags)) {
-            if ((rc = run_coarse_pass(bank, inv_norm, meta, qptr, now, N, D, nqb, k, idx_base,
+            if ((rc = run_coarse_pass(bank, bank_bf16, inv_norm, meta, qptr, now, N, D, nqb, k, idx_base,
                                       out_scores + qb0 * k, out_idx + qb0 * k, w, overflow_out,
                                       qb0 == 0, s)))
                 return rc;
@@ -1932,6 +1935,40 @@ int aura_knn_search_ex(const float* bank, const float* inv_norm, const float* me
         if ((rc = launch_select(fin, 1, nqb, s))) return rc;
     }
     return AURA_OK;
+}
+
+int aura_knn_search_ex(const float* bank, const float* inv_norm, const float* meta, const float* loc,
+                       int spatial_dims, const float* queries, const float* q_loc, float now,
+                       int64_t N, int64_t D, int64_t nq, int k, int32_t idx_base, float* out_scores,
+                       int32_t* out_idx, void* workspace, int64_t workspace_bytes, int flags,
+                       int32_t* overflow_out, const float* centroids, int nprobe, void* stream) {
+    return knn_search_impl(bank, nullptr, inv_norm, meta, loc, spatial_dims, queries, q_loc, now, N, D, nq,
+                           k, idx_base, out_scores, out_idx, workspace, workspace_bytes, flags,
+                           overflow_out, centroids, nprobe, stream);
+}
+
+int aura_knn_search_shadow(const float* bank, const uint16_t* bank_bf16, const float* inv_norm,
+                           const float* meta, const float* queries, float now, int64_t N, int64_t D,
+                           int64_t nq, int k, int32_t idx_base, float* out_scores, int32_t* out_idx,
+                           void* workspace, int64_t workspace_bytes, int flags, int32_t* overflow_out,
+                           void* stream) {
+    return knn_search_impl(bank, bank_bf16, inv_norm, meta, nullptr, 0, queries, nullptr, now, N, D, nq, k,
+                           idx_base, out_scores, out_idx, workspace, workspace_bytes, flags, overflow_out,
+                           nullptr, 0, stream);
+}
+
+int aura_bank_shadow_update(const float* bank, uint16_t* bank_bf16, const int64_t* slots, int64_t row0,
+                            int64_t n, int64_t D, void* stream) {
+    if (n < 0 || D <= 0 || (D & 7) || row0 < 0) return AURA_E_INVAL;
+    if (n == 0) return AURA_OK;
+    if (!bank || !bank_bf16) return AURA_E_INVAL;
+    if ((reinterpret_cast<uintptr_t>(bank) & 15) || (reinterpret_cast<uintptr_t>(bank_bf16) & 15)) return AURA_E_ALIGN;
+    const int64_t work = n * (D / 8);
+    int64_t blocks = (work + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(bank_shadow_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       bank, bank_bf16, slots, row0, n, D);
+    return check_launch();
 }
 
 int aura_knn_search(const float* bank, const float* inv_norm, const float* meta, const float* loc,

@@ -56,6 +56,7 @@ constexpr int RF_ROWS = 16;              // survivors per wave and round
 
 struct CoarseArgs {
     const float* bank;
+    const uint16_t* bank16;  // optional bf16 shadow of the bank (SRC16 kernels), row-major [N][D]
     const float4* rowc;      // [N] per-row score constants {A, B_up, B_lo, -} (coarse_prep_kernel)
     const uint16_t* qhat;    // bf16 query fragments, [nq/256][4 waves][4 blocks][KS][64 lanes][8]
     const float* inv_q;      // [nq]
@@ -250,12 +251,15 @@ __global__ __launch_bounds__(256) void coarse_threshold_kernel(const float* __re
     }
 }
 
-template <int KS, int MODE>
+// SRC16 = rows come from the bf16 shadow of the bank (half the HBM bytes, half the LDS-DMA writes,
+// one ds_read_b128 per k-step and no convert); otherwise from the fp32 bank.
+template <int KS, int MODE, bool SRC16>
 __global__ __launch_bounds__(CS_THREADS) void coarse_scan_kernel(const CoarseArgs a) {
-    static_assert(KS % 2 == 0, "KS pieces are dealt 4 waves x KS/2");
-    constexpr int TILE_BYTES = KS * 2048;                  // 16 rows x KS*32 floats
+    static_assert(KS % 4 == 0, "pieces are dealt over 4 waves");
+    constexpr int STEP_BYTES = SRC16 ? 1024 : 2048;        // one k-step (32 k) of 16 rows
+    constexpr int TILE_BYTES = KS * STEP_BYTES;
     constexpr int SLOT_BYTES = TILE_BYTES + CS_AUX_BYTES;
-    constexpr int NP = KS / 2;                             // bank pieces per wave and tile
+    constexpr int NP = SRC16 ? KS / 4 : KS / 2;            // bank pieces (1 KiB each) per wave and tile
     constexpr int GL = NP + 1;                             // global_load_lds per wave and tile
     extern __shared__ __attribute__((aligned(16))) char csmem[];
     uint32_t* const s_buf = reinterpret_cast<uint32_t*>(csmem + CS_SLOTS * SLOT_BYTES);  // [2][CS_BUF/2][3]
@@ -273,33 +277,41 @@ __global__ __launch_bounds__(CS_THREADS) void coarse_scan_kernel(const CoarseArg
     if (tid < 2) s_nb[tid] = 0;
     __syncthreads();
 
-    // reader offsets inside a k-step block: chunks 2g and 2g+1 of row lr, XOR-swizzled
-    const int sw = (lr >> 1) & 7;
-    const int off0 = (8 * lr + ((2 * lg) ^ sw)) * 16;
-    const int off1 = (8 * lr + ((2 * lg + 1) ^ sw)) * 16;
-    // loader roles: piece m = wave + 4 i -> k-step m>>1 = (wave>>1) + 2 i, row half m&1 = wave&1 (the
-    // same for all of a wave's pieces); lane -> row rho = 8 half + lane/8, 16-byte chunk cch of the
-    // 128-byte line (the image is swizzled by choosing WHICH chunk a lane fetches: LDS-DMA writes
-    // lane-linear).  A wave's pieces are 256 bytes apart in the row, so one offset register serves
-    // them all.  Columns beyond D re-read the row's last 16 bytes: finite data times the queries'
-    // zero padding (ragged D only; clamped per piece).
-    const uint32_t ld_rho = 8 * (wave & 1) + (lane >> 3);
-    const uint32_t ld_cch = (lane & 7) ^ ((ld_rho >> 1) & 7);
-    const uint32_t ld_kf0 = 32 * (wave >> 1) + 4 * ld_cch;          // floats; piece i: + 64 i
-    const uint32_t voff0 = (ld_rho * D + ld_kf0) * 4u;              // bytes from the tile's first row
+    // Reader offsets inside a k-step block (lane = row lr, k-group lg), XOR-swizzled so that the 16
+    // lanes of a ds_read_b128 phase hit 16 different bank quads:
+    //   fp32 image: 8 chunks of 16 B per row (128 B); the lane reads chunks 2 lg and 2 lg + 1
+    //   bf16 image: 4 chunks of 16 B per row ( 64 B); the lane reads chunk lg
+    const int sw = SRC16 ? (lr >> 2) & 3 : (lr >> 1) & 7;
+    const int off0 = SRC16 ? (4 * lr + (lg ^ sw)) * 16 : (8 * lr + ((2 * lg) ^ sw)) * 16;
+    const int off1 = SRC16 ? 0 : (8 * lr + ((2 * lg + 1) ^ sw)) * 16;
+    // Loader roles.  The image is swizzled by choosing WHICH 16-byte chunk a lane fetches (LDS-DMA
+    // writes lane-linear).  A wave's pieces are 256 bytes apart in the row either way, so one offset
+    // register serves them all.  Columns beyond D re-read the row's last 16 bytes: finite data times
+    // the queries' zero padding (ragged D only; clamped per piece).
+    //   fp32: piece m = wave + 4 i -> k-step m>>1, row half m&1 (fixed per wave); lane -> row
+    //         8 half + lane/8, chunk (lane&7) ^ swizzle of the 128-byte line
+    //   bf16: piece m = wave + 4 i -> k-step m; lane -> row lane/4, chunk (lane&3) ^ swizzle of the
+    //         64-byte half line
+    const uint32_t ld_rho = SRC16 ? (uint32_t)(lane >> 2) : 8 * (wave & 1) + (lane >> 3);
+    const uint32_t ld_cch = SRC16 ? (lane & 3) ^ ((ld_rho >> 2) & 3) : (lane & 7) ^ ((ld_rho >> 1) & 7);
+    constexpr uint32_t ESZ = SRC16 ? 2 : 4, ECH = SRC16 ? 8 : 4;    // element bytes, elements per chunk
+    const uint32_t ld_kf0 = (SRC16 ? 32 * wave : 32 * (wave >> 1)) + ECH * ld_cch;   // elements; piece i: + 256 B
+    const uint32_t voff0 = (ld_rho * D + ld_kf0) * ESZ;             // bytes from the tile's first row
     const bool full_k = D == (uint32_t)(KS * 32);
+    const char* const src = SRC16 ? reinterpret_cast<const char*>(a.bank16) : reinterpret_cast<const char*>(a.bank);
 
     auto tile_row0 = [&](int64_t j) -> int64_t {
         if (MODE == CS_MODE_SAMPLE) return ((j >> 3) * a.tile_step) * 128 + (j & 7) * 16;
         return j * 16;
     };
     auto issue = [&](int64_t j, int slot) {
-        char* const sb = csmem + slot * SLOT_BYTES + (wave & 1) * 1024 + (wave >> 1) * 2048;
+        char* const sb = csmem + slot * SLOT_BYTES +
+                         (SRC16 ? wave * 1024 : (wave & 1) * 1024 + (wave >> 1) * 2048);
         const int64_t r0 = tile_row0(j);
-        const char* base = reinterpret_cast<const char*>(a.bank + r0 * (int64_t)D);
+        const char* base = src + r0 * (int64_t)D * ESZ;
         if (r0 + CS_ROWS > a.N) {                          // last, partial tile: clamp the row
             const uint32_t last = (uint32_t)(a.N - 1 - r0);
-            if (ld_rho > last) base -= (int64_t)(ld_rho - last) * D * 4;
+            if (ld_rho > last) base -= (int64_t)(ld_rho - last) * D * ESZ;
         }
         if (full_k) {
 #pragma unroll
@@ -307,12 +319,12 @@ __global__ __launch_bounds__(CS_THREADS) void coarse_scan_kernel(const CoarseArg
                 glds16(reinterpret_cast<const float*>(base + voff0 + 256 * i), sb + i * 4096);
         } else {
             uint32_t kf0 = ld_kf0;
-            asm volatile("" : "+v"(kf0));                  // recompute per call: hoisting these 12
+            asm volatile("" : "+v"(kf0));                  // recompute per call: hoisting these
 #pragma unroll                                             // addresses out of the tile loop spills
             for (int i = 0; i < NP; ++i) {
-                uint32_t kf = kf0 + 64 * i;
-                if (kf >= D) kf = D - 4;
-                glds16(reinterpret_cast<const float*>(base + (ld_rho * D + kf) * 4u), sb + i * 4096);
+                uint32_t kf = kf0 + (256 / ESZ) * i;
+                if (kf >= D) kf = D - ECH;
+                glds16(reinterpret_cast<const float*>(base + (ld_rho * D + kf) * ESZ), sb + i * 4096);
             }
         }
         {   // row constants (every wave issues the same piece: uniform vmcnt, same bytes)
@@ -325,7 +337,8 @@ __global__ __launch_bounds__(CS_THREADS) void coarse_scan_kernel(const CoarseArg
     // candidate buffer: two halves; tile t appends to half t&1, so the other half is stable during
     // tile t and can be inspected / flushed without any extra barrier
     constexpr int HALF = CS_BUF / 2;
-    const uint32_t nb_addr = lds_addr(s_nb), buf_addr = lds_addr(s_buf);
+    const uint32_t nb_addr = lds_addr(s_nb), cs_base = lds_addr(csmem);
+    const uint32_t buf_addr = cs_base + CS_SLOTS * SLOT_BYTES;
     auto flush_half = [&](int h, int nb) {                 // all threads; nb uniform
         const int n = nb < HALF ? nb : HALF;
         for (int i = tid; i < n; i += CS_THREADS) {
@@ -427,20 +440,26 @@ __global__ __launch_bounds__(CS_THREADS) void coarse_scan_kernel(const CoarseArg
             if (!(a.dbg & 1)) {
 #pragma unroll
             for (int s = 0; s < 2 && s < KS; ++s) {
-                xr[s][0] = *reinterpret_cast<const f32x4v*>(sb + s * 2048 + off0);
-                xr[s][1] = *reinterpret_cast<const f32x4v*>(sb + s * 2048 + off1);
+                xr[s][0] = *reinterpret_cast<const f32x4v*>(sb + s * STEP_BYTES + off0);
+                if (!SRC16) xr[s][1] = *reinterpret_cast<const f32x4v*>(sb + s * STEP_BYTES + off1);
             }
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 if (s + 2 < KS) {
-                    xr[(s + 2) % 3][0] = *reinterpret_cast<const f32x4v*>(sb + (s + 2) * 2048 + off0);
-                    xr[(s + 2) % 3][1] = *reinterpret_cast<const f32x4v*>(sb + (s + 2) * 2048 + off1);
+                    xr[(s + 2) % 3][0] = *reinterpret_cast<const f32x4v*>(sb + (s + 2) * STEP_BYTES + off0);
+                    if (!SRC16)
+                        xr[(s + 2) % 3][1] = *reinterpret_cast<const f32x4v*>(sb + (s + 2) * STEP_BYTES + off1);
                 }
-                const f32x4v x0 = xr[s % 3][0], x1 = xr[s % 3][1];
-                f32x8v x;
-                x[0] = x0[0]; x[1] = x0[1]; x[2] = x0[2]; x[3] = x0[3];
-                x[4] = x1[0]; x[5] = x1[1]; x[6] = x1[2]; x[7] = x1[3];
-                const bf16x8v af = __builtin_convertvector(x, bf16x8v);
+                bf16x8v af;
+                if (SRC16) {
+                    af = __builtin_bit_cast(bf16x8v, xr[s % 3][0]);
+                } else {
+                    const f32x4v x0 = xr[s % 3][0], x1 = xr[s % 3][1];
+                    f32x8v x;
+                    x[0] = x0[0]; x[1] = x0[1]; x[2] = x0[2]; x[3] = x0[3];
+                    x[4] = x1[0]; x[5] = x1[1]; x[6] = x1[2]; x[7] = x1[3];
+                    af = __builtin_convertvector(x, bf16x8v);
+                }
 #pragma unroll
                 for (int b = 0; b < CS_QB; ++b) {
                     if (b * KS + s < CS_QA) {
@@ -453,11 +472,11 @@ __global__ __launch_bounds__(CS_THREADS) void coarse_scan_kernel(const CoarseArg
                 }
                 // the epilogue's row constants are fetched behind the last two k-steps
                 if (s == (KS >= 3 ? KS - 3 : 0))
-                    lds_read4x16_nowait(lds_addr(sb + TILE_BYTES) + lg * 64, rcv[0], rcv[1], rcv[2], rcv[3]);
+                    lds_read4x16_nowait(cs_base + slot * SLOT_BYTES + TILE_BYTES + lg * 64, rcv[0], rcv[1], rcv[2], rcv[3]);
                 __builtin_amdgcn_sched_barrier(0);
             }
             } else {
-                lds_read4x16_nowait(lds_addr(sb + TILE_BYTES) + lg * 64, rcv[0], rcv[1], rcv[2], rcv[3]);
+                lds_read4x16_nowait(cs_base + slot * SLOT_BYTES + TILE_BYTES + lg * 64, rcv[0], rcv[1], rcv[2], rcv[3]);
             }
             lds_wait4(rcv[0], rcv[1], rcv[2], rcv[3]);
             __builtin_amdgcn_sched_barrier(0);
@@ -512,29 +531,42 @@ __global__ __launch_bounds__(CS_THREADS) void coarse_scan_kernel(const CoarseArg
                     const int q = qoff + 16 * b + lr;
                     if (lg == 0 && q < a.nq) a.gmax[(int64_t)q * a.gmax_ld + (j0 + t)] = mx;
                 }
-            } else if (bits != 0u && !(a.dbg & 32)) {
-                int p = lds_add_rtn(nb_addr + par * 4, __popc(bits));
-                const uint32_t bufa = buf_addr + par * (HALF * 12);
+            } else if (!(a.dbg & 32)) {
+                // Candidate append, one entry per lane and round: a lane emits its lowest pending
+                // (query block, row) pair; the wave reserves the round's slots with ONE LDS atomic.
+                // Most lanes have nothing and most of the others exactly one pair, so a wave-tile
+                // usually takes a single round (the 16-way per-bit branching this replaces cost
+                // more than the MFMA loop's converts).
+                unsigned rem = bits;
+                for (;;) {
+                    const unsigned long long m = __ballot(rem != 0u);
+                    if (m == 0ull) break;
+                    const int first = __ffsll((long long)m) - 1;
+                    int base = 0;
+                    if (lane == first) base = lds_add_rtn(nb_addr + par * 4, __popcll(m));
+                    base = __builtin_amdgcn_readlane(base, first);
+                    if (rem != 0u) {
+                        const int idx = __ffs(rem) - 1;      // = 4 b + e
+                        float u = acc[0][0];
 #pragma unroll
-                for (int b = 0; b < CS_QB; ++b) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if ((bits >> (b * 4 + e)) & 1u) {
-                            const int q = qoff + 16 * b + lr;
-                            if (p < HALF) {
-                                lds_write3(bufa + p * 12, (uint32_t)q, (uint32_t)(r0 + 4 * lg + e),
-                                           __float_as_uint(acc[b][e]));
-                            } else {
-                                // burst beyond the buffer (e.g. a run of fresh rows that every query
-                                // wants): straight to the query's list; slow (drains the prefetch) but exact
-                                const int gp = atomicAdd(a.cnt + (int64_t)q * CNT_STRIDE, 1);
-                                if (gp < a.cap) {
-                                    a.cand_scores[(int64_t)q * a.cap + gp] = acc[b][e];
-                                    a.cand_idx[(int64_t)q * a.cap + gp] = (int32_t)(r0 + 4 * lg + e);
-                                }
+                        for (int i = 1; i < 16; ++i) u = idx == i ? acc[i >> 2][i & 3] : u;
+                        const int p = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
+                                          __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                        const int q = qoff + 16 * (idx >> 2) + lr;
+                        const int row = (int)r0 + 4 * lg + (idx & 3);
+                        if (p < HALF) {
+                            lds_write3(buf_addr + par * (HALF * 12) + p * 12, (uint32_t)q, (uint32_t)row,
+                                       __float_as_uint(u));
+                        } else {
+                            // burst beyond the buffer (e.g. a run of fresh rows that every query
+                            // wants): straight to the query's list; slow (drains the prefetch) but exact
+                            const int gp = atomicAdd(a.cnt + (int64_t)q * CNT_STRIDE, 1);
+                            if (gp < a.cap) {
+                                a.cand_scores[(int64_t)q * a.cap + gp] = u;
+                                a.cand_idx[(int64_t)q * a.cap + gp] = row;
                             }
-                            ++p;
                         }
+                        rem &= rem - 1u;
                     }
                 }
             }
@@ -750,28 +782,50 @@ inline bool coarse_eligible(const float* bank, const float* queries, const float
     return true;
 }
 
-template <int KS>
+template <int KS, bool SRC16>
 inline int launch_coarse(const CoarseArgs& a, int mode, int grid, hipStream_t s) {
-    const size_t lds = (size_t)CS_SLOTS * (KS * 2048 + CS_AUX_BYTES) + (size_t)CS_BUF * 12;
+    const size_t lds = (size_t)CS_SLOTS * (KS * (SRC16 ? 1024 : 2048) + CS_AUX_BYTES) + (size_t)CS_BUF * 12;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(coarse_scan_kernel<KS, CS_MODE_SAMPLE>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(coarse_scan_kernel<KS, CS_MODE_SAMPLE, SRC16>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(coarse_scan_kernel<KS, CS_MODE_FILTER>),
+            hipFuncSetAttribute(reinterpret_cast<const void*>(coarse_scan_kernel<KS, CS_MODE_FILTER, SRC16>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return AURA_E_LAUNCH;
         attr_set = true;
     }
     if (mode == CS_MODE_SAMPLE)
-        hipLaunchKernelGGL((coarse_scan_kernel<KS, CS_MODE_SAMPLE>), dim3(grid), dim3(CS_THREADS), lds, s, a);
+        hipLaunchKernelGGL((coarse_scan_kernel<KS, CS_MODE_SAMPLE, SRC16>), dim3(grid), dim3(CS_THREADS), lds, s, a);
     else
-        hipLaunchKernelGGL((coarse_scan_kernel<KS, CS_MODE_FILTER>), dim3(grid), dim3(CS_THREADS), lds, s, a);
+        hipLaunchKernelGGL((coarse_scan_kernel<KS, CS_MODE_FILTER, SRC16>), dim3(grid), dim3(CS_THREADS), lds, s, a);
     return check_launch();
 }
 
 inline int dispatch_coarse(const CoarseArgs& a, int mode, int grid, hipStream_t s) {
     const int64_t ks = (a.D + 31) / 32;
-    if (ks <= 8) return launch_coarse<8>(a, mode, grid, s);
-    if (ks <= 16) return launch_coarse<16>(a, mode, grid, s);
-    return launch_coarse<24>(a, mode, grid, s);
+    if (a.bank16) {
+        if (ks <= 8) return launch_coarse<8, true>(a, mode, grid, s);
+        if (ks <= 16) return launch_coarse<16, true>(a, mode, grid, s);
+        return launch_coarse<24, true>(a, mode, grid, s);
+    }
+    if (ks <= 8) return launch_coarse<8, false>(a, mode, grid, s);
+    if (ks <= 16) return launch_coarse<16, false>(a, mode, grid, s);
+    return launch_coarse<24, false>(a, mode, grid, s);
+}
+
+// bf16 shadow rows: shadow[r] = bf16(bank[r]) for r in slots[0..n) or [row0, row0 + n)
+__global__ __launch_bounds__(256) void bank_shadow_kernel(const float* __restrict__ bank,
+                                                          uint16_t* __restrict__ shadow,
+                                                          const int64_t* __restrict__ slots, int64_t row0,
+                                                          int64_t n, int64_t D) {
+    const int64_t per = D / 8;                               // 16-byte output chunks per row
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n * per; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / per, c = i - r * per;
+        const int64_t row = slots ? slots[r] : row0 + r;
+        const float4 u = *reinterpret_cast<const float4*>(bank + row * D + 8 * c);
+        const float4 w = *reinterpret_cast<const float4*>(bank + row * D + 8 * c + 4);
+        f32x8v x;
+        x[0] = u.x; x[1] = u.y; x[2] = u.z; x[3] = u.w; x[4] = w.x; x[5] = w.y; x[6] = w.z; x[7] = w.w;
+        *reinterpret_cast<bf16x8v*>(shadow + row * D + 8 * c) = __builtin_convertvector(x, bf16x8v);
+    }
 }

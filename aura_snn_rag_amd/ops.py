@@ -210,6 +210,23 @@ def bank_row_norms(bank, inv_norm, row0: int, n: int) -> None:
           "aura_bank_row_norms")
 
 
+def bank_shadow_update(bank, shadow, row0: int = 0, n: Optional[int] = None, slots=None) -> None:
+    """shadow[r] = bf16(bank[r]) for the rows ``slots`` (int64 [n], device) or [row0, row0 + n)."""
+    _need(bank, "bank", torch.float32); _need(shadow, "shadow", torch.bfloat16)
+    M, D = bank.shape
+    if shadow.shape != bank.shape or D % 8:
+        raise ValueError("bank_shadow_update: shadow must match the bank and D % 8 == 0")
+    if slots is not None:
+        _need(slots, "slots", torch.int64)
+        n = slots.numel()
+    elif n is None:
+        n = M - row0
+    if row0 < 0 or n < 0 or (slots is None and row0 + n > M):
+        raise ValueError("bank_shadow_update: range out of bounds")
+    check(lib().aura_bank_shadow_update(_p(bank), _p(shadow), _p(slots), row0, n, D, _stream()),
+          "aura_bank_shadow_update")
+
+
 def bank_write(bank, loc, meta, inv_norm, feats, slots, cur_loc, now: float,
                centroids=None, centroid_counts=None, eff_k: int = 0) -> None:
     """Write feats[n, D] into rows ``slots`` (int64 [n], device)."""
@@ -257,7 +274,7 @@ def _workspace(device, nbytes: int) -> torch.Tensor:
 def knn_search(bank, inv_norm, meta, queries, k: int, now: float, count: Optional[int] = None,
                loc=None, q_loc=None, idx_base: int = 0, force_dense: bool = False,
                centroids=None, nprobe: int = 0, check_overflow: bool = True,
-               fp32_scan: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+               fp32_scan: bool = False, shadow=None) -> Tuple[torch.Tensor, torch.Tensor]:
     """Exact batched recall over rows [0, count) -> (scores [nq, k] fp32, idx [nq, k] int32).
 
     ``centroids`` (256 x D) + ``nprobe`` switches on the reference's centroid-candidate
@@ -301,7 +318,18 @@ def knn_search(bank, inv_norm, meta, queries, k: int, now: float, count: Optiona
     if ovf is None:
         ovf = _ovf_flags[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
 
+    use_shadow = shadow is not None and q_loc is None and centroids is None
+    if use_shadow:
+        _need(shadow, "shadow", torch.bfloat16)
+        if shadow.shape != bank.shape:
+            raise ValueError("knn_search: shadow must have the bank's shape")
+
     def run(flags):
+        if use_shadow:
+            check(L.aura_knn_search_shadow(_p(bank), _p(shadow), _p(inv_norm), _p(meta), _p(queries), now,
+                                           N, D, nq, k, idx_base, _p(out_s), _p(out_i), base, nbytes,
+                                           flags, _p(ovf), _stream()), "aura_knn_search_shadow")
+            return
         check(L.aura_knn_search_ex(_p(bank), _p(inv_norm), _p(meta), _p(loc), sd, _p(queries),
                                    _p(q_loc), now, N, D, nq, k, idx_base, _p(out_s), _p(out_i),
                                    base, nbytes, flags, _p(ovf), _p(centroids), nprobe, _stream()),

@@ -262,9 +262,16 @@ def main():
     q = torch.cat([bank[pick.to(dev)] + 0.05 * torch.randn(nq // 2, D, generator=g).to(dev),
                    torch.randn(nq - nq // 2, D, generator=g).to(dev)]).contiguous()
 
-    def local_search(qq, kk, check=False, fp32_scan=False):
+    # bf16 shadow of the rows, kept beside the bank like 1/||row|| (HippocampalFormation maintains
+    # both on every write): the two-stage recall's prefilter streams it instead of the fp32 rows
+    shadow = None
+    if D % 8 == 0 and D <= 768 and rows >= 8192:
+        shadow = torch.empty(rows, D, dtype=torch.bfloat16, device=dev)
+        ops.bank_shadow_update(bank, shadow)
+
+    def local_search(qq, kk, check=False, fp32_scan=False, use_shadow=True):
         return ops.knn_search(bank, inv, meta, qq, kk, now, count=rows, idx_base=r0, check_overflow=check,
-                              fp32_scan=fp32_scan)
+                              fp32_scan=fp32_scan, shadow=shadow if use_shadow else None)
 
     recall = ShardedRecall(local_search, ops.topk_merge)
 
@@ -316,14 +323,18 @@ def main():
         common = {"traffic": None, "avg_kernel_ms": avg_ms, "launches_timed": n,
                   "rows_per_launch": scanned_rows, "queries_per_launch": nq_launch,
                   "launches_per_step": n / steps}
-        if lib.aura_profile_last_scan_kind() == 1:
-            nbytes = scanned_rows * (D * 4 + 16)
+        kind = lib.aura_profile_last_scan_kind()
+        if kind in (1, 2):
+            esz = 2 if kind == 2 else 4                      # bf16 shadow rows / fp32 rows
+            nbytes = scanned_rows * (D * esz + 16)
             gbs = nbytes / (avg_ms * 1e-3) / 1e9
             return dict(common, bound="hbm",
-                        kernel="coarse_scan_kernel<KS,FILTER> (bank rows streamed once by global_load_lds, "
-                               "v_mfma_f32_16x16x32_bf16 against register-resident query fragments)",
+                        kernel=f"coarse_scan_kernel<KS,FILTER,{'bf16 shadow' if kind == 2 else 'fp32'} rows> "
+                               "(rows streamed once by global_load_lds, v_mfma_f32_16x16x32_bf16 against "
+                               "register-resident query fragments)",
                         achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS,
-                        algorithmic_bytes_per_launch=nbytes, pmc_key="coarse_scan_kernel<24, 1>",
+                        algorithmic_bytes_per_launch=nbytes,
+                        pmc_key="coarse_scan_kernel<24, 1, true>" if kind == 2 else "coarse_scan_kernel<24, 1, false>",
                         bf16_tflops_at_kernel=tf, bf16_frac_of_2500=tf / 2500.0)
         return dict(common, bound="mfma",
                     kernel="knn_scan_filter_v2 (v_mfma_f32_32x32x2_f32, fp32 in / fp32 acc)",
@@ -370,6 +381,21 @@ def main():
         r2 = roofline_of(buf2, n2, args.steps)
         add_traffic(r2)
         fp32_line = {"retrievals_per_s": nq * args.steps / el, "ms_per_step": el / args.steps * 1e3, "roofline": r2}
+        if shadow is not None:                               # two-stage path streaming the fp32 rows
+            for _ in range(3):
+                local_search(q, k, use_shadow=False)
+            torch.cuda.synchronize()
+            lib.aura_profile_begin(max(1, args.steps * 4))
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                local_search(q, k, use_shadow=False)
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t1
+            n3 = lib.aura_profile_end(buf2, args.steps * 4)
+            r3 = roofline_of(buf2, n3, args.steps)
+            add_traffic(r3)
+            fp32_line["two_stage_without_shadow"] = {"retrievals_per_s": nq * args.steps / el,
+                                                     "ms_per_step": el / args.steps * 1e3, "roofline": r3}
 
     out = {
         "metric": "retrievals/sec", "value": value, "unit": "retrievals/s", "n_gpus": world,
@@ -379,8 +405,9 @@ def main():
         "config": {"workload": f"episodic cosine-kNN recall: {args.bank_rows}x{D} fp32 bank "
                                f"({'row-sharded over %d ranks' % world if world > 1 else 'one GPU'}), "
                                f"{nq}-query batch per rank, top-{k}, exact fp32 scores (bf16 matrix-core "
-                               f"prefilter with a proven error bound + fp32 re-scoring of the survivors: "
-                               f"rows and score bits identical to the all-fp32 scan)",
+                               f"prefilter over a bf16 shadow of the rows with a proven error bound + fp32 "
+                               f"re-scoring of the survivors from the fp32 bank: rows and score bits "
+                               f"identical to the all-fp32 scan)",
                    "bank_rows": args.bank_rows, "dim": D, "queries_per_rank": nq, "k": k,
                    "parallelism": f"bank-sharded x{world}" if world > 1 else "single"},
         "planted_neighbours_found": planted_ok,

@@ -174,7 +174,8 @@ int aura_profile_end(float* ms_out_host, int max_out);
 /* Bank rows and queries scored by the most recent profiled main-scan launch (HOST pointers):
  * the units behind bench.py's algorithmic FLOP count, 2 * rows * nq * D per launch. */
 int aura_profile_last_scan(int64_t* rows_out, int64_t* nq_out);
-/* 0 = the profiled launch was the fp32 matrix scan, 1 = the bf16 prefilter scan. */
+/* 0 = the profiled launch was the fp32 matrix scan, 1 = the bf16 prefilter scan over the fp32 bank,
+ * 2 = the prefilter scan over the bf16 shadow. */
 int aura_profile_last_scan_kind(void);
 
 /* Merge S per-shard top-k lists into the global top-k (the step after the RCCL all-gather,
@@ -198,6 +199,23 @@ int aura_kmeans_update(const float* bank, const int32_t* assign, float* centroid
  * (memory_augmented_layer.py:124-128). */
 int aura_bank_gather(const float* bank, const int32_t* idx, float* out, int64_t n, int64_t D,
                      void* stream);
+
+/* Optional bf16 shadow of the bank for the two-stage recall's prefilter (halves the bytes the
+ * prefilter streams; results unchanged: the survivors are still re-scored from the fp32 bank).
+ * [build-side] no upstream counterpart; the product keeps it beside memory_features
+ * (src/core/hippocampal.py:88) exactly as it keeps 1/||row||.
+ * aura_bank_shadow_update: bank_bf16[r] = bf16(bank[r]) for r in slots[0..n) (device int64) or,
+ * with slots == NULL, [row0, row0 + n).  D % 8 == 0, both bases 16-byte aligned. */
+int aura_bank_shadow_update(const float* bank, uint16_t* bank_bf16, const int64_t* slots, int64_t row0,
+                            int64_t n, int64_t D, void* stream);
+
+/* aura_knn_search_ex without location term / centroid mask, with the shadow (may be NULL = same as
+ * aura_knn_search_ex).  The shadow must hold bf16(bank[r]) for every r < N. */
+int aura_knn_search_shadow(const float* bank, const uint16_t* bank_bf16, const float* inv_norm,
+                           const float* meta, const float* queries, float now, int64_t N, int64_t D,
+                           int64_t nq, int k, int32_t idx_base, float* out_scores, int32_t* out_idx,
+                           void* workspace, int64_t workspace_bytes, int flags, int32_t* overflow_out,
+                           void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Surrogate-gradient training path and the prosody-modulated GIF (fp32, [rows][T][H] layout)

@@ -39,7 +39,7 @@ def bank_decay(meta, rate, count):
 
 
 def knn_search(bank, inv_norm, meta, queries, k, now, count=None, loc=None, q_loc=None, idx_base=0,
-               force_dense=False, centroids=None, nprobe=0, check_overflow=True):
+               force_dense=False, centroids=None, nprobe=0, check_overflow=True, fp32_scan=False, shadow=None):
     N = bank.shape[0] if count is None else count
     nq = queries.shape[0]
     scores = torch.full((nq, k), float("-inf"))

@@ -407,6 +407,57 @@ def test_two_stage_equals_fp32_scan(dev, N, D, nq, k, kind):
     ri, rs = O.knn_exact_batch(bank, meta[:, 0], meta[:, 1], q[sub], k, NOW)
     _, _, ok = topk_equivalent(i1[sub], s1[sub], ri, rs)
     assert ok
+    if D % 8 == 0:                                   # prefilter over the bf16 shadow of the bank
+        from aura_snn_rag_amd import ops
+        b = bank.to(dev).contiguous()
+        shadow = torch.empty(N, D, dtype=torch.bfloat16, device=dev)
+        ops.bank_shadow_update(b, shadow)
+        assert torch.equal(shadow, b.to(torch.bfloat16))
+        inv = torch.empty(N, device=dev)
+        ops.bank_row_norms(b, inv, 0, N)
+        s2, i2 = ops.knn_search(b, inv, meta.to(dev).contiguous(), q.to(dev).contiguous(), k, NOW, shadow=shadow)
+        assert torch.equal(i0, i2) and torch.equal(s0, s2)
+
+
+def test_bank_shadow_follows_writes(dev):
+    """HippocampalFormation keeps the bf16 shadow current across appends, ring overwrites and
+    state_dict loads: recall is bit-identical to a bank that never uses the shadow."""
+    from aura_snn_rag_amd.core.hippocampal import HippocampalFormation
+    D, M = 64, 12000
+    g = torch.Generator().manual_seed(11)
+    feats = torch.randn(15000, D, generator=g)
+    kw = dict(feature_dim=D, max_memories=M, n_place_cells=8, n_time_cells=4, n_grid_cells=4, device="cuda",
+              use_centroid_index=False, overflow="fifo")
+    a, b = HippocampalFormation(**kw), HippocampalFormation(bf16_shadow=False, **kw)
+    q = feats[torch.randint(0, 9000, (33,), generator=g)] + 0.1 * torch.randn(33, D, generator=g)
+
+    def same(now):
+        sa, ra = a.recall_batch(q, k=12, now=now)
+        sb, rb = b.recall_batch(q, k=12, now=now)
+        assert torch.equal(ra, rb) and torch.equal(sa, sb)
+    for hf in (a, b):
+        hf.bulk_write(feats[:9000], rebuild=False)
+    b.memory_metadata.copy_(a.memory_metadata)                      # same write timestamps
+    now = float(a.memory_metadata[0, 1].item()) + 5.0
+    same(now)
+    assert a._shadow is not None and a._shadow_valid_upto == 9000 and b._shadow is None
+    for hf in (a, b):                                               # appends past the watermark
+        hf.create_episodic_memories([f"x{i}" for i in range(500)], feats[9000:9500])
+    b.memory_metadata.copy_(a.memory_metadata)
+    same(now)
+    for hf in (a, b):                                               # fills the bank, then overwrites rows 0..
+        hf.create_episodic_memories([f"y{i}" for i in range(4000)], feats[9500:13500])
+    b.memory_metadata.copy_(a.memory_metadata)
+    assert a.memory_count == M
+    same(now)
+    assert torch.equal(a._shadow[:M], a.memory_features[:M].to(torch.bfloat16))
+    a.memory_features[:100].mul_(-1.0)                              # direct edit + documented refresh
+    b.memory_features[:100].mul_(-1.0)
+    a.refresh_norms(); b.refresh_norms()
+    same(now)
+    sd = {k_: v.clone() for k_, v in b.state_dict().items()}
+    a.load_state_dict(sd)                                           # load invalidates norms and shadow
+    same(now)
 
 
 def test_two_stage_ties_and_overflow_fallback(dev):

@@ -43,10 +43,20 @@ def main():
         torch.cuda.synchronize()
         same_i = bool((i0 == i1).all()); same_s = bool((s0 == s1).all())
         ovf = int(ops._ovf_flags[dev].item())
+        sh_txt = ""
+        if D % 8 == 0:
+            shadow = torch.empty(N, D, dtype=torch.bfloat16, device=dev)
+            ops.bank_shadow_update(bank, shadow)
+            assert torch.equal(shadow, bank.to(torch.bfloat16))
+            s2, i2 = ops.knn_search(bank, inv, meta, q, k, now, check_overflow=False, shadow=shadow)
+            ok2 = bool((i0 == i2).all()) and bool((s0 == s2).all())
+            ovf2 = int(ops._ovf_flags[dev].item())
+            t_s = timed(lambda: ops.knn_search(bank, inv, meta, q, k, now, check_overflow=False, shadow=shadow))
+            sh_txt = f" | shadow: equal={ok2} overflow={ovf2} {t_s*1e3:.1f}us"
         t_f = timed(lambda: ops.knn_search(bank, inv, meta, q, k, now, fp32_scan=True, check_overflow=False))
         t_c = timed(lambda: ops.knn_search(bank, inv, meta, q, k, now, check_overflow=False))
         print(f"N={N} D={D} nq={nq} k={k} clustered={cl}: idx_equal={same_i} score_equal={same_s} overflow={ovf} "
-              f"fp32={t_f*1e3:.1f}us coarse={t_c*1e3:.1f}us  maxdiff={(s0-s1).abs().max().item():.3e}", flush=True)
+              f"fp32={t_f*1e3:.1f}us coarse={t_c*1e3:.1f}us  maxdiff={(s0-s1).abs().max().item():.3e}" + sh_txt, flush=True)
         if not same_i:
             bad = (i0 != i1).any(1).nonzero().flatten()[:3]
             for b in bad.tolist():
