@@ -1695,17 +1695,24 @@ inline int run_coarse_pass(const float* bank, const uint16_t* bank16, const floa
     r.cand_scores = w.cand_scores; r.cand_idx = w.cand_idx; r.cap = w.cap; r.idx_base = idx_base;
     r.out_scores = out_scores; r.out_idx = out_idx; r.overflow = overflow_out;
     const int64_t Dpad = (D + 31) / 32 * 32;
-    size_t lds = (size_t)8 * RF_ROWS * (RF_KC + 4) * 4 + (size_t)Dpad * 4;
-    if (lds < (size_t)RF_CAP * 12) lds = (size_t)RF_CAP * 12;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(coarse_refine_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize,
-                                8 * RF_ROWS * (RF_KC + 4) * 4 + 768 * 4) != hipSuccess)
-            return AURA_E_LAUNCH;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(coarse_refine_kernel, dim3((unsigned)nqb), dim3(RF_THREADS), lds, s, r);
+    auto launch_refine = [&](auto rows_tag, auto kc_tag) -> int {
+        constexpr int ROWS = decltype(rows_tag)::value, KC = decltype(kc_tag)::value;
+        size_t lds = (size_t)8 * ROWS * (KC + 4) * 4 + (size_t)Dpad * 4;
+        if (lds < (size_t)RF_CAP * 12) lds = (size_t)RF_CAP * 12;
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(coarse_refine_kernel<ROWS, KC>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    8 * ROWS * (KC + 4) * 4 + 768 * 4) != hipSuccess)
+                return AURA_E_LAUNCH;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((coarse_refine_kernel<ROWS, KC>), dim3((unsigned)nqb), dim3(RF_THREADS), lds, s, r);
+        return AURA_OK;
+    };
+    if (nqb > cus) rc = launch_refine(std::integral_constant<int, 10>{}, std::integral_constant<int, 192>{});
+    else rc = launch_refine(std::integral_constant<int, 16>{}, std::integral_constant<int, 256>{});
+    if (rc) return rc;
     return check_launch();
 }
 

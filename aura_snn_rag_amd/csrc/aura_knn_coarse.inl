@@ -51,8 +51,11 @@ constexpr int COARSE_MAX_K = 256;
 constexpr int RF_THREADS = 512;
 constexpr int RF_CAP = 4096;             // candidates per query the refine kernel holds in LDS
 constexpr int RF_SURV = 1024;            // survivors re-scored per query at most
-constexpr int RF_KC = 256;               // k-chunk of the re-scoring stage
-constexpr int RF_ROWS = 16;              // survivors per wave and round
+// re-scoring geometry (template parameters of coarse_refine_kernel): survivors per wave and round x
+// k-chunk.  <16, 256>: 133 KB of LDS, one workgroup per CU, 3 chunks -- passes with at most one query
+// per CU.  <10, 192>: 66 KB, two workgroups per CU, 4 chunks -- larger passes (e.g. the row-sharded
+// multi-GPU layout, where a rank refines every rank's queries).  Survivors are dealt round-robin so
+// the usual ~70 keep all 8 waves busy in either geometry.
 
 struct CoarseArgs {
     const float* bank;
@@ -607,6 +610,7 @@ struct RefineArgs {
     int32_t* overflow;
 };
 
+template <int RF_ROWS, int RF_KC>
 __global__ __launch_bounds__(RF_THREADS) void coarse_refine_kernel(const RefineArgs a) {
     extern __shared__ __attribute__((aligned(16))) char rsmem[];
     // phase A: candidate arrays; phase B (aliases A): per-wave row chunks + the query
@@ -691,7 +695,7 @@ __global__ __launch_bounds__(RF_THREADS) void coarse_refine_kernel(const RefineA
     if (ovf && tid == 0 && a.overflow) atomicOr(a.overflow, ovf_bits);   // which list overflowed
     __syncthreads();     // candidate arrays are dead from here: rsmem is reused below
 
-    // ---- exact re-scoring: wave w takes survivors w*16 .. w*16+15 of each round of 128 ----
+    // ---- exact re-scoring: rounds of 8 x RF_ROWS survivors, survivor base + 8 r + w -> wave w, slot r ----
     // k order of the fp32 scan (knn_scan_filter_v2): inside each group of 8 consecutive k the
     // MFMA chain visits 0,4,1,5,2,6,3,7; D is padded with zeros to a multiple of 32.
     constexpr int RSTRIDE = RF_KC + 4;                       // floats; 16-B aligned, conflict-free
@@ -701,16 +705,17 @@ __global__ __launch_bounds__(RF_THREADS) void coarse_refine_kernel(const RefineA
     for (int64_t i = tid; i < Dpad; i += RF_THREADS) s_q[i] = i < D ? a.queries[(int64_t)q * D + i] : 0.0f;
     __syncthreads();
     const float iq = a.inv_q[q];
+    const bool ld_lane = lane * 4 < RF_KC;                   // lanes that move a row chunk
     for (int base = 0; base < S; base += 8 * RF_ROWS) {
-        const int mine = base + wave * RF_ROWS;              // first survivor of this wave
-        const int cntw = (S - mine) < RF_ROWS ? (S - mine) : RF_ROWS;   // may be <= 0
+        int cntw = (S - base - wave + 7) / 8;                // survivors of this wave in this round
+        cntw = cntw < 0 ? 0 : (cntw > RF_ROWS ? RF_ROWS : cntw);
         if (cntw <= 0) continue;                             // wave-uniform
         const float* rowp[RF_ROWS];
 #pragma unroll
         for (int r = 0; r < RF_ROWS; ++r)
-            rowp[r] = r < cntw ? a.bank + (int64_t)s_surv[mine + r] * D + lane * 4 : nullptr;
+            rowp[r] = (r < cntw && ld_lane) ? a.bank + (int64_t)s_surv[base + 8 * r + wave] * D + lane * 4 : nullptr;
         float4 pre[RF_ROWS];
-        auto fetch = [&](int64_t k0) {                       // chunk [k0, k0+256): lane -> 16 bytes
+        auto fetch = [&](int64_t k0) {                       // chunk [k0, k0 + RF_KC): lane -> 16 bytes
 #pragma unroll
             for (int r = 0; r < RF_ROWS; ++r) {
                 pre[r] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -721,9 +726,11 @@ __global__ __launch_bounds__(RF_THREADS) void coarse_refine_kernel(const RefineA
         fetch(0);
         for (int64_t k0 = 0; k0 < Dpad; k0 += RF_KC) {
             const int kc = (int)((Dpad - k0) < RF_KC ? (Dpad - k0) : RF_KC);
+            if (ld_lane) {
 #pragma unroll
-            for (int r = 0; r < RF_ROWS; ++r)
-                *reinterpret_cast<float4*>(s_rows + r * RSTRIDE + lane * 4) = pre[r];
+                for (int r = 0; r < RF_ROWS; ++r)
+                    *reinterpret_cast<float4*>(s_rows + r * RSTRIDE + lane * 4) = pre[r];
+            }
             if (k0 + RF_KC < Dpad) fetch(k0 + RF_KC);        // next chunk flies during the chain
             __builtin_amdgcn_wave_barrier();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -746,13 +753,14 @@ __global__ __launch_bounds__(RF_THREADS) void coarse_refine_kernel(const RefineA
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         if (lane < cntw) {
-            const int32_t row = s_surv[mine + lane];
+            const int si = base + 8 * lane + wave;
+            const int32_t row = s_surv[si];
             const float inv_m = a.inv_norm[row];
             const float4 m = *reinterpret_cast<const float4*>(a.meta + (int64_t)row * 4);
             const float tw = 0.2f * expf(-(a.now - m.y) / 3600.0f);
             const float sim = acc * iq * inv_m;
             const float comb = (0.5f * sim + tw) * m.x;
-            s_key[mine + lane] = ((unsigned long long)ord_key(comb) << 32) | (uint32_t)(~(uint32_t)row);
+            s_key[si] = ((unsigned long long)ord_key(comb) << 32) | (uint32_t)(~(uint32_t)row);
         }
     }
     __syncthreads();
