@@ -419,6 +419,13 @@ def test_two_stage_equals_fp32_scan(dev, N, D, nq, k, kind):
         assert torch.equal(i0, i2) and torch.equal(s0, s2)
 
 
+def test_two_stage_random_sweep(dev):
+    """16 random (N, D, nq, k, data kind, metadata kind) cases: both prefilter sources must agree
+    with the all-fp32 scan bit for bit (tools/two_stage_fuzz.py runs longer sweeps)."""
+    from tools.two_stage_fuzz import sweep
+    assert sweep(cases=16, seed=2026, dev=dev, verbose=False) == 0
+
+
 def test_bank_shadow_follows_writes(dev):
     """HippocampalFormation keeps the bf16 shadow current across appends, ring overwrites and
     state_dict loads: recall is bit-identical to a bank that never uses the shadow."""
