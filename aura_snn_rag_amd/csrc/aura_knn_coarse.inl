@@ -265,7 +265,7 @@ __global__ __launch_bounds__(CS_THREADS) void coarse_scan_kernel(const CoarseArg
     constexpr int NP = SRC16 ? KS / 4 : KS / 2;            // bank pieces (1 KiB each) per wave and tile
     constexpr int GL = NP + 1;                             // global_load_lds per wave and tile
     extern __shared__ __attribute__((aligned(16))) char csmem[];
-    uint32_t* const s_buf = reinterpret_cast<uint32_t*>(csmem + CS_SLOTS * SLOT_BYTES);  // [2][CS_BUF/2][3]
+    // candidate buffer [2][CS_BUF/2][3] follows the slots (addressed through buf_addr)
     __shared__ int s_nb[2];
 
     const int tid = threadIdx.x;
@@ -342,18 +342,32 @@ __global__ __launch_bounds__(CS_THREADS) void coarse_scan_kernel(const CoarseArg
     constexpr int HALF = CS_BUF / 2;
     const uint32_t nb_addr = lds_addr(s_nb), cs_base = lds_addr(csmem);
     const uint32_t buf_addr = cs_base + CS_SLOTS * SLOT_BYTES;
-    auto flush_half = [&](int h, int nb) {                 // all threads; nb uniform
-        const int n = nb < HALF ? nb : HALF;
-        for (int i = tid; i < n; i += CS_THREADS) {
-            const uint32_t* e = s_buf + (h * HALF + i) * 3;
-            const int q = (int)e[0];
-            const int p = atomicAdd(a.cnt + (int64_t)q * CNT_STRIDE, 1);
-            if (p < a.cap) {
-                a.cand_scores[(int64_t)q * a.cap + p] = __uint_as_float(e[2]);
-                a.cand_idx[(int64_t)q * a.cap + p] = (int32_t)e[1];
+    // span-end write-out of both halves: every slot reservation is issued before any is waited for
+    // (up to 4 entries per thread), then one wait, then the stores
+    auto flush_all = [&](int n0, int n1) {
+        n0 = n0 < HALF ? n0 : HALF;
+        n1 = n1 < HALF ? n1 : HALF;
+        int pos[4];
+        uint32_t eq[4], er[4], eu[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = tid + (u & 1) * CS_THREADS, h = u >> 1;
+            pos[u] = -1;
+            if (i < (h ? n1 : n0)) {
+                lds_read3(buf_addr + (h * HALF + i) * 12, eq[u], er[u], eu[u]);
+                gatomic_inc_nowait(a.cnt + (int64_t)eq[u] * CNT_STRIDE, pos[u]);
             }
         }
-        if (tid == 0) s_nb[h] = 0;                           // (entries beyond HALF went out directly)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(pos[0]), "+v"(pos[1]), "+v"(pos[2]), "+v"(pos[3])::"memory");
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = tid + (u & 1) * CS_THREADS, h = u >> 1;
+            if (i < (h ? n1 : n0) && pos[u] < a.cap) {
+                a.cand_scores[(int64_t)eq[u] * a.cap + pos[u]] = __uint_as_float(eu[u]);
+                a.cand_idx[(int64_t)eq[u] * a.cap + pos[u]] = (int32_t)er[u];
+            }
+        }
+        if (tid < 2) lds_write_i32(nb_addr + tid * 4, 0);
     };
 
     int64_t c = lo;
@@ -580,8 +594,7 @@ __global__ __launch_bounds__(CS_THREADS) void coarse_scan_kernel(const CoarseArg
         if (MODE == CS_MODE_FILTER) {                       // span end: both halves go out
             const int n0 = __builtin_amdgcn_readfirstlane(lds_read_i32(nb_addr));
             const int n1 = __builtin_amdgcn_readfirstlane(lds_read_i32(nb_addr + 4));
-            if (n0 > 0) flush_half(0, n0);
-            if (n1 > 0) flush_half(1, n1);
+            if (n0 > 0 || n1 > 0) flush_all(n0, n1);
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
