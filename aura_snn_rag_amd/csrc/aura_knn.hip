@@ -774,18 +774,21 @@ __global__ __launch_bounds__(SCAN_THREADS) void knn_scan_filter_v2(const ScanArg
 // 252 us for 256 queries; this split takes ~20 us.)
 // ------------------------------------------------------------------------------------------
 constexpr int PD_Q = 8, PD_C = 64;
+constexpr int PD_BK = 128;                 // k-chunk per barrier pair (was 32: 48 barriers per launch
+constexpr int PD_STRIDE = PD_BK + 4;       // made the 0.1 GFLOP kernel take 30 us); 132-float rows keep
+                                           // the per-lane ds_read_b128 of 64 rows conflict-free
 
 __global__ __launch_bounds__(256) void centroid_dist_kernel(const float* __restrict__ centroids,
                                                             const float* __restrict__ queries,
                                                             int64_t D, int nq,
                                                             float* __restrict__ dist) {
-    __shared__ __attribute__((aligned(16))) float Cs[PD_C * LDS_STRIDE];
-    __shared__ __attribute__((aligned(16))) float Qs[PD_Q * LDS_STRIDE];
+    __shared__ __attribute__((aligned(16))) float Cs[PD_C * PD_STRIDE];
+    __shared__ __attribute__((aligned(16))) float Qs[PD_Q * PD_STRIDE];
     const int tid = threadIdx.x;
     const int c0 = blockIdx.x * PD_C, q0 = blockIdx.y * PD_Q;
     const int cl = tid & 63, qs = (tid >> 6) * 2;      // this thread: centroid cl x queries qs, qs+1
-    // staging slots: centroid tile 64 rows x 8 float4 = 512 (2 per thread), query tile 8 x 8 = 64
-    const int r0 = tid >> 3, col = (tid & 7) * 4;
+    // staging: a row chunk is 32 float4; thread -> (row r0 + 8 i, float4 column tid & 31)
+    const int r0 = tid >> 5, col = (tid & 31) * 4;
     const bool vec = (D & 3) == 0;
     auto ld = [&](const float* base, int64_t k0) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -800,22 +803,27 @@ __global__ __launch_bounds__(256) void centroid_dist_kernel(const float* __restr
         }
         return v;
     };
-    const float* cb0 = centroids + (int64_t)(c0 + r0) * D;
-    const float* cb1 = centroids + (int64_t)(c0 + r0 + 32) * D;
-    const float* qb = (tid < 64 && q0 + r0 < nq) ? queries + (int64_t)(q0 + r0) * D : nullptr;
-    float4 p0 = ld(cb0, 0), p1 = ld(cb1, 0), p2 = ld(qb, 0);
-    float acc0 = 0.0f, acc1 = 0.0f;
-    for (int64_t k0 = 0; k0 < D; k0 += BK) {
-        *reinterpret_cast<float4*>(Cs + r0 * LDS_STRIDE + col) = p0;
-        *reinterpret_cast<float4*>(Cs + (r0 + 32) * LDS_STRIDE + col) = p1;
-        if (tid < 64) *reinterpret_cast<float4*>(Qs + r0 * LDS_STRIDE + col) = p2;
-        __syncthreads();
-        if (k0 + BK < D) { p0 = ld(cb0, k0 + BK); p1 = ld(cb1, k0 + BK); p2 = ld(qb, k0 + BK); }
+    const float* qb = q0 + r0 < nq ? queries + (int64_t)(q0 + r0) * D : nullptr;   // rows 0..7 = all 256 threads
+    float4 pc[8], pq;
 #pragma unroll
-        for (int j = 0; j < BK / 4; ++j) {
-            const float4 c = *reinterpret_cast<const float4*>(Cs + cl * LDS_STRIDE + 4 * j);
-            const float4 a = *reinterpret_cast<const float4*>(Qs + qs * LDS_STRIDE + 4 * j);
-            const float4 b = *reinterpret_cast<const float4*>(Qs + (qs + 1) * LDS_STRIDE + 4 * j);
+    for (int i = 0; i < 8; ++i) pc[i] = ld(centroids + (int64_t)(c0 + r0 + 8 * i) * D, 0);
+    pq = ld(qb, 0);
+    float acc0 = 0.0f, acc1 = 0.0f;
+    for (int64_t k0 = 0; k0 < D; k0 += PD_BK) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(Cs + (r0 + 8 * i) * PD_STRIDE + col) = pc[i];
+        *reinterpret_cast<float4*>(Qs + r0 * PD_STRIDE + col) = pq;
+        __syncthreads();
+        if (k0 + PD_BK < D) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) pc[i] = ld(centroids + (int64_t)(c0 + r0 + 8 * i) * D, k0 + PD_BK);
+            pq = ld(qb, k0 + PD_BK);
+        }
+#pragma unroll 8
+        for (int j = 0; j < PD_BK / 4; ++j) {           // zero-padded beyond D: (0 - 0)^2 adds nothing
+            const float4 c = *reinterpret_cast<const float4*>(Cs + cl * PD_STRIDE + 4 * j);
+            const float4 a = *reinterpret_cast<const float4*>(Qs + qs * PD_STRIDE + 4 * j);
+            const float4 b = *reinterpret_cast<const float4*>(Qs + (qs + 1) * PD_STRIDE + 4 * j);
             float d;
             d = c.x - a.x; acc0 = fmaf(d, d, acc0);  d = c.y - a.y; acc0 = fmaf(d, d, acc0);
             d = c.z - a.z; acc0 = fmaf(d, d, acc0);  d = c.w - a.w; acc0 = fmaf(d, d, acc0);
