@@ -1635,7 +1635,8 @@ inline int run_coarse_pass(const float* bank, const uint16_t* bank16, const floa
     int rc;
     // sample: strided 128-row logical tiles (8 coarse tiles each), sized as for the fp32 path
     int64_t sample_rows = (int64_t)k * N / 512;
-    int64_t floor_rows = N / 8 < 8192 ? N / 8 : 8192;
+    static const int64_t sample_cap = getenv("AURA_CS_SAMPLE_ROWS") ? atoll(getenv("AURA_CS_SAMPLE_ROWS")) : 8192;
+    int64_t floor_rows = N / 8 < sample_cap ? N / 8 : sample_cap;
     if (floor_rows < (int64_t)k * 48) floor_rows = (int64_t)k * 48;
     if (sample_rows < floor_rows) sample_rows = floor_rows;
     const int64_t ntiles128 = N / 128;                       // whole logical tiles only
