@@ -1314,11 +1314,17 @@ __global__ __launch_bounds__(SEL_THREADS) void topk_select_kernel(const SelectAr
             idx = a.src_idx[off];
         } else {
             idx = a.row_begin + (j / a.blk) * (int64_t)a.blk * a.step + j % a.blk;
-            if (idx >= a.row_end) { s = -INFINITY; idx = 0x7fffffff; }
+            if (idx >= a.row_end) s = -INFINITY;
         }
-        // -inf marks "not a candidate" (masked by the centroid probe, out of range, padding)
-        if (idx < 0 || s == -INFINITY) { s = -INFINITY; idx = 0x7fffffff; }
-        s_keys[i] = ((unsigned long long)ord_key(s) << 32) | (0xffffffffu - (uint32_t)idx);
+        // -inf marks "not a candidate" (masked by the centroid probe, out of range, padding).  Such
+        // entries get the low word i (< 2^31, below every real row's 0xffffffff - idx) so that ALL
+        // keys of a chunk stay distinct: with one shared key, a chunk holding fewer than k
+        // candidates made "key >= k-th key" match more than k entries and which of them reached
+        // the k output slots was a race (lost real candidates for k >~ 100 with centroid masks).
+        if (idx < 0 || s == -INFINITY)
+            s_keys[i] = ((unsigned long long)ord_key(-INFINITY) << 32) | (uint32_t)i;
+        else
+            s_keys[i] = ((unsigned long long)ord_key(s) << 32) | (0xffffffffu - (uint32_t)idx);
     }
     const int k = a.k < n ? a.k : n;  // winners available in this chunk
     if (tid == 0) { s_prefix = 0ull; s_remaining = k; s_nwin = 0; s_done = 0; }
@@ -1398,9 +1404,10 @@ __global__ __launch_bounds__(SEL_THREADS) void topk_select_kernel(const SelectAr
             int32_t idx = -1;
             if (i < k) {
                 const unsigned long long key = s_win[i];
-                idx = (int32_t)(0xffffffffu - (uint32_t)key);
-                if (idx == 0x7fffffff) idx = -1;
-                else s = ord_unkey((uint32_t)(key >> 32));
+                if ((uint32_t)key >= 0x80000000u) {          // a real row (see the key construction)
+                    idx = (int32_t)(0xffffffffu - (uint32_t)key);
+                    s = ord_unkey((uint32_t)(key >> 32));
+                }
             }
             const int64_t o = (int64_t)q * a.dst_qs + a.dst_off + (int64_t)c * a.k + i;
             a.dst_scores[o] = s;
@@ -1435,12 +1442,9 @@ __global__ __launch_bounds__(SEL_THREADS) void topk_select_kernel(const SelectAr
         int32_t idx = -1;
         if (i < k) {
             const unsigned long long key = s_win[i];
-            idx = (int32_t)(0xffffffffu - (uint32_t)key);
-            if (idx == 0x7fffffff) {
-                idx = -1;  // padding / out-of-range column
-            } else {
+            if ((uint32_t)key >= 0x80000000u) {              // else: padding / masked / out-of-range column
+                idx = (int32_t)(0xffffffffu - (uint32_t)key) + a.idx_base;
                 s = ord_unkey((uint32_t)(key >> 32));
-                idx += a.idx_base;
             }
         }
         a.dst_scores[(int64_t)q * a.dst_qs + i] = s;
@@ -1624,6 +1628,29 @@ inline int dispatch_scan(const ScanArgs& a, int mode, int64_t ntiles_grid, hipSt
 }
 
 #include "aura_knn_coarse.inl"
+#include "aura_knn_ivf2.inl"
+
+// coarse_refine_kernel in the geometry that fits the pass (see the comment at the kernel)
+inline int launch_refine_for(const RefineArgs& r, int nqb, int64_t D, int cus, hipStream_t s) {
+    const int64_t Dpad = (D + 31) / 32 * 32;
+    auto launch_refine = [&](auto rows_tag, auto kc_tag) -> int {
+        constexpr int ROWS = decltype(rows_tag)::value, KC = decltype(kc_tag)::value;
+        size_t lds = (size_t)8 * ROWS * (KC + 4) * 4 + (size_t)Dpad * 4;
+        if (lds < (size_t)RF_CAP * 12) lds = (size_t)RF_CAP * 12;
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(coarse_refine_kernel<ROWS, KC>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    8 * ROWS * (KC + 4) * 4 + 768 * 4) != hipSuccess)
+                return AURA_E_LAUNCH;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((coarse_refine_kernel<ROWS, KC>), dim3((unsigned)nqb), dim3(RF_THREADS), lds, s, r);
+        return check_launch();
+    };
+    if (nqb > cus) return launch_refine(std::integral_constant<int, 10>{}, std::integral_constant<int, 192>{});
+    return launch_refine(std::integral_constant<int, 16>{}, std::integral_constant<int, 256>{});
+}
 
 // Two-stage recall of one query pass (see aura_knn_coarse.inl).  Returns AURA_OK after queuing
 // sample scan -> threshold -> filter scan -> refine; the caller skips the fp32 pipeline.
@@ -1704,25 +1731,7 @@ inline int run_coarse_pass(const float* bank, const uint16_t* bank16, const floa
     r.now = now; r.e_cos = e_cos; r.N = N; r.D = D; r.k = k; r.cnt = w.cnt;
     r.cand_scores = w.cand_scores; r.cand_idx = w.cand_idx; r.cap = w.cap; r.idx_base = idx_base;
     r.out_scores = out_scores; r.out_idx = out_idx; r.overflow = overflow_out;
-    const int64_t Dpad = (D + 31) / 32 * 32;
-    auto launch_refine = [&](auto rows_tag, auto kc_tag) -> int {
-        constexpr int ROWS = decltype(rows_tag)::value, KC = decltype(kc_tag)::value;
-        size_t lds = (size_t)8 * ROWS * (KC + 4) * 4 + (size_t)Dpad * 4;
-        if (lds < (size_t)RF_CAP * 12) lds = (size_t)RF_CAP * 12;
-        static bool attr_set = false;
-        if (!attr_set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(coarse_refine_kernel<ROWS, KC>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    8 * ROWS * (KC + 4) * 4 + 768 * 4) != hipSuccess)
-                return AURA_E_LAUNCH;
-            attr_set = true;
-        }
-        hipLaunchKernelGGL((coarse_refine_kernel<ROWS, KC>), dim3((unsigned)nqb), dim3(RF_THREADS), lds, s, r);
-        return AURA_OK;
-    };
-    if (nqb > cus) rc = launch_refine(std::integral_constant<int, 10>{}, std::integral_constant<int, 192>{});
-    else rc = launch_refine(std::integral_constant<int, 16>{}, std::integral_constant<int, 256>{});
-    if (rc) return rc;
+    if ((rc = launch_refine_for(r, nqb, D, cus, s))) return rc;
     return check_launch();
 }
 
@@ -1978,6 +1987,104 @@ int aura_knn_search_shadow(const float* bank, const uint16_t* bank_bf16, const f
     return knn_search_impl(bank, bank_bf16, inv_norm, meta, nullptr, 0, queries, nullptr, now, N, D, nq, k,
                            idx_base, out_scores, out_idx, workspace, workspace_bytes, flags, overflow_out,
                            centroids, nprobe, stream);
+}
+
+int64_t aura_knn_ivf2_workspace_bytes(int64_t n_sorted, int64_t nq, int k) {
+    if (n_sorted < 0 || nq < 0 || k <= 0) return -1;
+    return carve_ivf2(nullptr, n_sorted, nq, k).bytes;
+}
+
+int aura_bank_shadow_sorted(const float* bank, const int32_t* sorted_rows, uint16_t* sorted_bf16,
+                            int64_t n_sorted, int64_t D, void* stream) {
+    if (n_sorted < 0 || D <= 0 || (D & 7)) return AURA_E_INVAL;
+    if (n_sorted == 0) return AURA_OK;
+    if (!bank || !sorted_rows || !sorted_bf16) return AURA_E_INVAL;
+    if ((reinterpret_cast<uintptr_t>(bank) & 15) || (reinterpret_cast<uintptr_t>(sorted_bf16) & 15)) return AURA_E_ALIGN;
+    int64_t blocks = (n_sorted * (D / 8) + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(bank_shadow_sorted_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), bank, sorted_rows, sorted_bf16, n_sorted, D);
+    return check_launch();
+}
+
+int aura_knn_search_ivf2(const float* bank, const float* inv_norm, const float* meta,
+                         const uint16_t* sorted_bf16, const int32_t* sorted_rows, const int32_t* pad_off,
+                         const int32_t* list_len, int64_t n_sorted, const float* queries, float now,
+                         int64_t D, int64_t nq, int k,
+                         const float* centroids, int nprobe, int32_t idx_base, float* out_scores,
+                         int32_t* out_idx, void* workspace, int64_t workspace_bytes,
+                         int32_t* overflow_out, void* stream) {
+    if (n_sorted <= 0 || D <= 0 || D > 768 || (D & 7) || nq < 0 || k <= 0 || k > COARSE_MAX_K) return AURA_E_INVAL;
+    if (nprobe <= 0 || nprobe > 8) return AURA_E_INVAL;
+    if (nq == 0) return AURA_OK;
+    if (!bank || !inv_norm || !meta || !sorted_bf16 || !sorted_rows || !pad_off || !list_len || !queries || !centroids ||
+        !out_scores || !out_idx || !workspace)
+        return AURA_E_INVAL;
+    if ((reinterpret_cast<uintptr_t>(meta) & 15) || (reinterpret_cast<uintptr_t>(sorted_bf16) & 15) ||
+        (reinterpret_cast<uintptr_t>(queries) & 15) || (reinterpret_cast<uintptr_t>(bank) & 15))
+        return AURA_E_ALIGN;
+    if (reinterpret_cast<uintptr_t>(workspace) & 255) return AURA_E_ALIGN;
+    if (n_sorted > 0x7ffffff0LL || (n_sorted & 15)) return AURA_E_INVAL;
+    const Ivf2Workspace w = carve_ivf2(workspace, n_sorted, nq, k);
+    if (w.bytes > workspace_bytes) return AURA_E_INVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int KS = D <= 256 ? 8 : (D <= 512 ? 16 : 24);
+    const float e_cos = 0.00390625f * (1.0f + 0.001953125f) + 2.0f * (float)D * 5.9604645e-8f + 1e-5f;
+    const int cus = device_cu_count();
+    int rc;
+    for (int64_t qb0 = 0; qb0 < nq; qb0 += w.qp) {
+        const int nqb = (int)((nq - qb0) < w.qp ? (nq - qb0) : w.qp);
+        const float* qptr = queries + qb0 * D;
+        if ((rc = launch_probe(centroids, qptr, D, nqb, nprobe, w.probe_dist, w.probe, w.probe_ids, s))) return rc;
+        // per-list query lists (the fp32 lists path's preparation; its capacity bookkeeping is unused)
+        hipLaunchKernelGGL(ivf_prepare_kernel, dim3(1), dim3(256), 0, s, w.probe_ids, nprobe, nqb,
+                           list_len, w.lq_cnt, w.lq_list, w.qbase, w.cnt, w.item_off_old,
+                           w.work_counter, 0x7fffffff, 32, nullptr);
+        if ((rc = check_launch())) return rc;
+        hipLaunchKernelGGL(ivf2_plan_kernel, dim3(1), dim3(256), 0, s, w.lq_cnt, pad_off, w.blk_off,
+                           w.blk_list, w.blk_row0, w.blk_stride, w.item_off, w.sitem_off, w.nblk);
+        if ((rc = check_launch())) return rc;
+        const int qblocks = IVF2_MAXBLK * 256 / 4;
+        hipLaunchKernelGGL(ivf2_prep_kernel, dim3((unsigned)(qblocks + (n_sorted + 255) / 256)), dim3(256), 0, s,
+                           qptr, (int64_t)nqb, D, KS, w.lq_cnt, w.lq_list, w.blk_off, w.blk_list, w.nblk, w.qhat,
+                           w.inv_q, w.slotq, w.qslot, w.thr, qb0 == 0 ? overflow_out : nullptr, qblocks, meta,
+                           inv_norm, sorted_rows, n_sorted, now, e_cos, w.rowc);
+        if ((rc = check_launch())) return rc;
+
+        CoarseArgs c{};
+        c.bank = bank; c.bank16 = sorted_bf16; c.rowc = w.rowc; c.qhat = w.qhat; c.inv_q = w.inv_q;
+        c.N = n_sorted; c.D = D; c.nq = IVF2_MAXBLK * 256;
+        c.thr = w.thr; c.cnt = w.cnt; c.cand_scores = w.cand_scores; c.cand_idx = w.cand_idx; c.cap = w.cap;
+        c.blk_row0 = w.blk_row0; c.blk_stride = w.blk_stride; c.nblk = w.nblk; c.slotq = w.slotq;
+        c.gmax = w.gmax; c.gmax_ld = IVF2_STILES; c.item_off = w.sitem_off;
+        static const int cs_dbg = getenv("AURA_CS_DBG") ? atoi(getenv("AURA_CS_DBG")) : 0;
+        c.dbg = cs_dbg;
+        auto launch = [&](int mode) -> int {
+            if (KS == 8) return launch_coarse_ivf<8>(c, mode, cus, s);
+            if (KS == 16) return launch_coarse_ivf<16>(c, mode, cus, s);
+            return launch_coarse_ivf<24>(c, mode, cus, s);
+        };
+        if ((rc = launch(CS_MODE_SAMPLE))) return rc;
+        hipLaunchKernelGGL(ivf2_threshold_kernel, dim3((unsigned)((nqb + 3) / 4)), dim3(256), 0, s, w.gmax,
+                           w.qslot, w.blk_list, pad_off, nprobe, k, nqb, w.thr, w.cnt);
+        if ((rc = check_launch())) return rc;
+        c.gmax = nullptr; c.item_off = w.item_off;
+        const bool prof = g_prof.on && g_prof.used < g_prof.cap;
+        if (prof) {
+            (void)hipEventRecord(g_prof.start[g_prof.used], s);
+            g_prof.rows = n_sorted; g_prof.nq = nqb; g_prof.kind = 3;
+        }
+        if ((rc = launch(CS_MODE_FILTER))) return rc;
+        if (prof) (void)hipEventRecord(g_prof.stop[g_prof.used++], s);
+
+        RefineArgs r{};
+        r.bank = bank; r.inv_norm = inv_norm; r.meta = meta; r.queries = qptr; r.inv_q = w.inv_q;
+        r.now = now; r.e_cos = e_cos; r.N = 0; r.D = D; r.k = k; r.cnt = w.cnt;
+        r.cand_scores = w.cand_scores; r.cand_idx = w.cand_idx; r.cap = w.cap; r.idx_base = idx_base;
+        r.out_scores = out_scores + qb0 * k; r.out_idx = out_idx + qb0 * k; r.overflow = overflow_out;
+        if ((rc = launch_refine_for(r, nqb, D, cus, s))) return rc;
+    }
+    return AURA_OK;
 }
 
 int aura_bank_shadow_update(const float* bank, uint16_t* bank_bf16, const int64_t* slots, int64_t row0,

@@ -78,6 +78,17 @@ struct CoarseArgs {
     // probes centroid c; a row is a candidate only if its centroid id (rowc.w) is probed
     // (src/core/hippocampal.py:259-270)
     const uint32_t* probe_mask;
+    // IVF kernels (inverted lists over a LIST-SORTED bf16 shadow, every list padded to 16 rows): the
+    // "query blocks" are (list, 256 probing queries) blocks, the rows of block B are the contiguous
+    // sorted rows blk_row0[B] .. + 16 blk_tiles[B]; `thr` / `gmax` are indexed by block slot
+    // (B * 256 + slot), slotq maps a slot to its query (-1: unused), rowc.w holds the ORIGINAL row
+    // id's bits.  item_off[B] = first work item (tile) of block B, item_off[nblk] = total; all on
+    // the device so the host never syncs.
+    const int32_t* blk_row0;
+    const int32_t* blk_stride; // SAMPLE: sample tile j of block B is the block's tile j * blk_stride[B]
+    const int32_t* item_off;
+    const int32_t* nblk;     // [1]
+    const int32_t* slotq;    // [nblk * 256]
     int dbg;                 // AURA_CS_DBG timing ablations (results invalid when non-zero)
 };
 
@@ -262,9 +273,11 @@ __global__ __launch_bounds__(256) void coarse_threshold_kernel(const float* __re
 // one ds_read_b128 per k-step and no convert); otherwise from the fp32 bank.
 // MASKED = centroid-candidate mode: the 256 queries' probe masks (8 KB) sit in LDS behind the candidate
 // buffer (only the bf16-row variant has the room) and gate every (query, row) pair in the epilogue.
-template <int KS, int MODE, bool SRC16, bool MASKED>
+// IVF = inverted-list mode (see CoarseArgs): same scan, the work items are (block, tile) pairs.
+template <int KS, int MODE, bool SRC16, bool MASKED, bool IVF = false>
 __global__ __launch_bounds__(CS_THREADS) void coarse_scan_kernel(const CoarseArgs a) {
     static_assert(!MASKED || SRC16, "the probe masks need the LDS the bf16 rows leave free");
+    static_assert(!IVF || (SRC16 && !MASKED), "inverted lists run over the sorted bf16 shadow");
     static_assert(KS % 4 == 0, "pieces are dealt over 4 waves");
     constexpr int STEP_BYTES = SRC16 ? 1024 : 2048;        // one k-step (32 k) of 16 rows
     constexpr int TILE_BYTES = KS * STEP_BYTES;
@@ -281,7 +294,8 @@ __global__ __launch_bounds__(CS_THREADS) void coarse_scan_kernel(const CoarseArg
     const uint32_t D = (uint32_t)a.D;
 
     const int64_t nqblk = (a.nq + 255) / 256;
-    const int64_t total = a.n_tiles * nqblk;
+    const int ivf_nblk = IVF ? a.nblk[0] : 0;
+    const int64_t total = IVF ? (int64_t)a.item_off[ivf_nblk] : a.n_tiles * nqblk;
     const int64_t lo = total * (int64_t)blockIdx.x / gridDim.x;
     const int64_t hi = total * ((int64_t)blockIdx.x + 1) / gridDim.x;
     if (tid < 2) s_nb[tid] = 0;
@@ -310,7 +324,10 @@ __global__ __launch_bounds__(CS_THREADS) void coarse_scan_kernel(const CoarseArg
     const bool full_k = D == (uint32_t)(KS * 32);
     const char* const src = SRC16 ? reinterpret_cast<const char*>(a.bank16) : reinterpret_cast<const char*>(a.bank);
 
+    int64_t ivf_row0 = 0;                                  // IVF: first sorted row of the current block
+    int64_t ivf_step = 16;                                 // IVF: rows between consecutive work tiles
     auto tile_row0 = [&](int64_t j) -> int64_t {
+        if (IVF) return ivf_row0 + j * ivf_step;
         if (MODE == CS_MODE_SAMPLE) return ((j >> 3) * a.tile_step) * 128 + (j & 7) * 16;
         return j * 16;
     };
@@ -349,7 +366,7 @@ __global__ __launch_bounds__(CS_THREADS) void coarse_scan_kernel(const CoarseArg
     constexpr int HALF = CS_BUF / 2;
     const uint32_t nb_addr = lds_addr(s_nb), cs_base = lds_addr(csmem);
     const uint32_t buf_addr = cs_base + CS_SLOTS * SLOT_BYTES;
-    const uint32_t mask_addr = buf_addr + CS_BUF * 12;            // [256][8] probe masks (MASKED)
+    const uint32_t mask_addr = buf_addr + CS_BUF * 12;            // [256][8] probe masks (MASKED) / [256] slot -> query (IVF)
     // span-end write-out of both halves: every slot reservation is issued before any is waited for
     // (up to 4 entries per thread), then one wait, then the stores
     auto flush_all = [&](int n0, int n1) {
@@ -380,10 +397,30 @@ __global__ __launch_bounds__(CS_THREADS) void coarse_scan_kernel(const CoarseArg
 
     int64_t c = lo;
     while (c < hi) {
-        const int64_t qblk = c / a.n_tiles, j0 = c - qblk * a.n_tiles;
-        const int64_t seg = (hi - c) < (a.n_tiles - j0) ? (hi - c) : (a.n_tiles - j0);
+        int64_t qblk, j0, seg;
+        if (IVF) {
+            int blo = 0, bhi = ivf_nblk;                    // block B with item_off[B] <= c < item_off[B+1]
+            while (bhi - blo > 1) {
+                const int mid = (blo + bhi) >> 1;
+                if ((int64_t)a.item_off[mid] <= c) blo = mid; else bhi = mid;
+            }
+            qblk = blo;
+            j0 = c - a.item_off[blo];
+            const int64_t left = (int64_t)a.item_off[blo + 1] - c;
+            seg = (hi - c) < left ? (hi - c) : left;
+            ivf_row0 = a.blk_row0[blo];
+            ivf_step = MODE == CS_MODE_SAMPLE ? 16 * (int64_t)a.blk_stride[blo] : 16;   // sample: spread over the list
+        } else {
+            qblk = c / a.n_tiles; j0 = c - qblk * a.n_tiles;
+            seg = (hi - c) < (a.n_tiles - j0) ? (hi - c) : (a.n_tiles - j0);
+        }
         c += seg;
-        const int qoff = (int)qblk * 256 + wave * 64;      // this wave's first query
+        const int qoff = (int)qblk * 256 + wave * 64;      // this wave's first query (IVF: block slot)
+        if (IVF && MODE == CS_MODE_FILTER) {                // slot -> query table of this block -> LDS
+            int32_t* const s_sq = reinterpret_cast<int32_t*>(csmem + CS_SLOTS * SLOT_BYTES + CS_BUF * 12);
+            s_sq[tid] = a.slotq[qblk * 256 + tid];          // CS_THREADS == 256
+            __syncthreads();
+        }
 
         // ---- stationary operand: 64 (normalised) queries of this wave as bf16 B-fragments ----
         // one coalesced 16-byte load per lane and fragment, all in flight at once, landing in
@@ -589,7 +626,7 @@ __global__ __launch_bounds__(CS_THREADS) void coarse_scan_kernel(const CoarseArg
                     mx = fmaxf(mx, __shfl_xor(mx, 16));
                     mx = fmaxf(mx, __shfl_xor(mx, 32));
                     const int q = qoff + 16 * b + lr;
-                    if (lg == 0 && q < a.nq) a.gmax[(int64_t)q * a.gmax_ld + (j0 + t)] = mx;
+                    if (lg == 0 && q < a.nq) a.gmax[(int64_t)q * a.gmax_ld + (j0 + t)] = mx;   // IVF: tile of the block
                 }
             } else if (!(a.dbg & 32)) {
                 // Candidate append, one entry per lane and round: a lane emits its lowest pending
@@ -612,8 +649,16 @@ __global__ __launch_bounds__(CS_THREADS) void coarse_scan_kernel(const CoarseArg
                         for (int i = 1; i < 16; ++i) u = idx == i ? acc[i >> 2][i & 3] : u;
                         const int p = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
                                           __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                        const int q = qoff + 16 * (idx >> 2) + lr;
-                        const int row = (int)r0 + 4 * lg + (idx & 3);
+                        int q = qoff + 16 * (idx >> 2) + lr;
+                        int row = (int)r0 + 4 * lg + (idx & 3);
+                        if (IVF) {                           // slot -> query, sorted row -> bank row
+                            q = lds_read_i32(mask_addr + (uint32_t)((q & 255) * 4));
+                            float rb = rcv[0][3];
+                            rb = (idx & 3) == 1 ? rcv[1][3] : rb;
+                            rb = (idx & 3) == 2 ? rcv[2][3] : rb;
+                            rb = (idx & 3) == 3 ? rcv[3][3] : rb;
+                            row = __float_as_int(rb);
+                        }
                         if (p < HALF) {
                             lds_write3(buf_addr + par * (HALF * 12) + p * 12, (uint32_t)q, (uint32_t)row,
                                        __float_as_uint(u));

@@ -1,0 +1,275 @@
+// aura_knn_ivf2.inl -- centroid-index (inverted-list) recall through the two-stage scan.
+// Included by aura_knn.hip after aura_knn_coarse.inl and the IVF section (same translation unit).
+//
+// The reference restricts a query to the rows of its `nprobe` nearest centroids
+// (src/core/hippocampal.py:259-270).  aura_knn_search_ivf streams every probed list once per batch
+// on the fp32 matrix pipe and writes ALL candidate scores; here the same restriction runs on the
+// bf16 prefilter + fp32 re-scoring machinery of aura_knn_coarse.inl:
+//   * the caller keeps a LIST-SORTED bf16 shadow of the bank (rows grouped by centroid, every list
+//     padded to a multiple of 16 rows; `sorted_rows[i]` = bank row of sorted row i, -1 for pads),
+//     rebuilt whenever its inverted lists are (aura_bank_shadow_sorted);
+//   * a batch is regrouped BY LIST (ivf_prepare_kernel): block B = (list, up to 256 of the queries
+//     that probe it).  The block's queries are the scan's stationary bf16 fragments and the list's
+//     contiguous sorted rows stream past them, so a list is read once per batch whatever the batch
+//     size (coarse_scan_kernel<..., IVF>);
+//   * thresholds: a query's T is the k-th largest 16-row group maximum of L over IVF2_STILES tiles
+//     spread evenly over each of its lists (k distinct candidate rows score >= T; spread because
+//     rows inside a list are in write order and the score has a recency term);
+//   * candidates (U >= T) land in per-query lists with their ORIGINAL row ids and go through
+//     coarse_refine_kernel unchanged: tightened, re-scored in fp32 from the fp32 bank, ranked.
+// Results are bit-identical to aura_knn_search_ivf and to the masked scans (same candidate sets,
+// same fp32 arithmetic, ties to the lower row).
+
+constexpr int IVF2_STILES = 32;            // sample tiles (of 16 rows) per list
+constexpr int IVF2_MAXBLK = 256 + IVF_MAXQ * 8 / 256;   // blocks of one pass at most
+
+// ---- plan: blocks, their row ranges and the work-item prefixes (one workgroup) ----
+__global__ __launch_bounds__(256) void ivf2_plan_kernel(const int32_t* __restrict__ lq_cnt,
+                                                        const int32_t* __restrict__ pad_off,   // [257] padded row offsets
+                                                        int32_t* blk_off,    // [257] first block of each list
+                                                        int32_t* blk_list,   // [MAXBLK] list of block B
+                                                        int32_t* blk_row0,   // [MAXBLK]
+                                                        int32_t* blk_stride, // [MAXBLK] tiles between sample tiles
+                                                        int32_t* item_off,   // [MAXBLK + 1] filter items
+                                                        int32_t* sitem_off,  // [MAXBLK + 1] sample items
+                                                        int32_t* nblk) {
+    __shared__ int s_nb[257];
+    const int tid = threadIdx.x;
+    s_nb[tid + 1] = (lq_cnt[tid] + 255) / 256;
+    if (tid == 0) s_nb[0] = 0;
+    __syncthreads();
+    if (tid == 0)
+        for (int c = 1; c <= 256; ++c) s_nb[c] += s_nb[c - 1];
+    __syncthreads();
+    blk_off[tid] = s_nb[tid];
+    if (tid == 0) { blk_off[256] = s_nb[256]; nblk[0] = s_nb[256]; }
+    const int tiles = (pad_off[tid + 1] - pad_off[tid]) / 16;
+    for (int b = s_nb[tid]; b < s_nb[tid + 1]; ++b) {
+        blk_list[b] = tid;
+        blk_row0[b] = pad_off[tid];
+        blk_stride[b] = tiles > IVF2_STILES ? tiles / IVF2_STILES : 1;   // sample tiles j * stride, j < 32
+    }
+    __syncthreads();
+    if (tid == 0) {                                       // <= 320 blocks: a serial prefix is fine
+        int it = 0, st = 0;
+        for (int c = 0; c < 256; ++c) {
+            const int tl = (pad_off[c + 1] - pad_off[c]) / 16;
+            for (int b = s_nb[c]; b < s_nb[c + 1]; ++b) {
+                item_off[b] = it; sitem_off[b] = st;
+                it += tl; st += tl < IVF2_STILES ? tl : IVF2_STILES;
+            }
+        }
+        item_off[s_nb[256]] = it; sitem_off[s_nb[256]] = st;
+    }
+}
+
+// ---- prep: per block slot the query's bf16 fragments, the slot <-> query maps, +inf thresholds;
+//      per sorted row the score constants (with the bank row id's bits in .w) ----
+__global__ __launch_bounds__(256) void ivf2_prep_kernel(const float* __restrict__ x, int64_t nq, int64_t D, int KS,
+                                                        const int32_t* __restrict__ lq_cnt,
+                                                        const int32_t* __restrict__ lq_list,
+                                                        const int32_t* __restrict__ blk_off,
+                                                        const int32_t* __restrict__ blk_list,
+                                                        const int32_t* __restrict__ nblk,
+                                                        uint16_t* __restrict__ qhat, float* __restrict__ inv,
+                                                        int32_t* __restrict__ slotq, int32_t* __restrict__ qslot,
+                                                        uint32_t* __restrict__ thr, int32_t* overflow,
+                                                        int qblocks, const float* __restrict__ meta,
+                                                        const float* __restrict__ inv_norm,
+                                                        const int32_t* __restrict__ sorted_rows, int64_t Npad,
+                                                        float now, float e_cos, float4* __restrict__ rowc) {
+    if ((int)blockIdx.x >= qblocks) {
+        const int64_t i = ((int64_t)blockIdx.x - qblocks) * 256 + threadIdx.x;
+        if (i >= Npad) return;
+        const int32_t row = sorted_rows[i];
+        if (row < 0) {                                    // padding row: can never reach a threshold
+            rowc[i] = make_float4(0.0f, -INFINITY, -INFINITY, __int_as_float(-1));
+            return;
+        }
+        const float4 m = *reinterpret_cast<const float4*>(meta + (int64_t)row * 4);
+        const float strength = m.x;
+        const float tw = 0.2f * expf(-(now - m.y) / 3600.0f);
+        const float err = 0.5f * e_cos * fabsf(strength);
+        const float A = 0.5f * inv_norm[row] * strength;
+        rowc[i] = make_float4(A, tw * strength + err, tw * strength - err, __int_as_float(row));
+        return;
+    }
+    const int lane = threadIdx.x & 63;
+    const int64_t vs = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);     // virtual slot = B * 256 + slot
+    if (overflow && blockIdx.x == 0 && threadIdx.x == 0) *overflow = 0;
+    const int B = (int)(vs >> 8);
+    if (B >= nblk[0]) return;
+    const int list = blk_list[B];
+    const int ls = (B - blk_off[list]) * 256 + (int)(vs & 255);           // slot inside the list's query list
+    const bool used = ls < lq_cnt[list];
+    int q = -1, p = 0;
+    if (used) {
+        const int packed = lq_list[(int64_t)list * IVF_MAXQ + ls];
+        q = packed >> 4; p = packed & 15;
+    }
+    if (lane == 0) {
+        slotq[vs] = q;
+        thr[vs] = 0xff800000u;                             // ord_key(+inf): nothing passes until the
+        if (used) qslot[(int64_t)q * 8 + p] = (int32_t)vs; // threshold kernel lowers it
+    }
+    const int wq = (int)(vs >> 6) & 3, b = (int)(vs >> 4) & 3, lr = (int)vs & 15;
+    uint16_t* const base = qhat + (((((int64_t)B * 4 + wq) * 4 + b) * KS) * 64 + lr) * 8;
+    float s = 0.0f;
+    if (used)
+        for (int64_t i = lane * 4; i < D; i += 256) {      // 1/||q|| with query_prep_kernel's arithmetic
+            const float4 u = *reinterpret_cast<const float4*>(x + (int64_t)q * D + i);
+            s = fmaf(u.x, u.x, s); s = fmaf(u.y, u.y, s); s = fmaf(u.z, u.z, s); s = fmaf(u.w, u.w, s);
+        }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    const float iqv = 1.0f / fmaxf(sqrtf(s), 1e-12f);
+    if (lane == 0 && used) inv[q] = iqv;                   // (written by each of the query's 8 slots: same value)
+    for (int c = lane; c < KS * 4; c += 64) {
+        f32x8v v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.0f;
+        const int64_t k0 = 8 * (int64_t)c;
+        if (used && k0 < D) {
+            const float4 u = *reinterpret_cast<const float4*>(x + (int64_t)q * D + k0);
+            v[0] = u.x * iqv; v[1] = u.y * iqv; v[2] = u.z * iqv; v[3] = u.w * iqv;
+            if (k0 + 4 < D) {
+                const float4 w = *reinterpret_cast<const float4*>(x + (int64_t)q * D + k0 + 4);
+                v[4] = w.x * iqv; v[5] = w.y * iqv; v[6] = w.z * iqv; v[7] = w.w * iqv;
+            }
+        }
+        *reinterpret_cast<bf16x8v*>(base + ((int64_t)(c >> 2) * 64 + (c & 3) * 16) * 8) =
+            __builtin_convertvector(v, bf16x8v);
+    }
+}
+
+// ---- thresholds: one wave per query over the group maxima of its nprobe lists' sample tiles ----
+__global__ __launch_bounds__(256) void ivf2_threshold_kernel(const float* __restrict__ gmax,       // [slots][STILES]
+                                                             const int32_t* __restrict__ qslot,    // [nq][8]
+                                                             const int32_t* __restrict__ blk_list,
+                                                             const int32_t* __restrict__ pad_off,
+                                                             int nprobe, int k, int nq,
+                                                             uint32_t* __restrict__ thr,
+                                                             int32_t* __restrict__ cnt_out) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    // lane -> probe lane>>3, sample tiles 4 (lane&7) .. +3
+    const int p = lane >> 3;
+    uint32_t key[4] = {0u, 0u, 0u, 0u};
+    int vs = -1;
+    if (p < nprobe) {
+        vs = qslot[(int64_t)q * 8 + p];
+        const int list = blk_list[vs >> 8];
+        const int tiles = (pad_off[list + 1] - pad_off[list]) / 16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int g = 4 * (lane & 7) + i;
+            if (g < tiles && g < IVF2_STILES) key[i] = ord_key(gmax[(int64_t)vs * IVF2_STILES + g]);
+        }
+    }
+    uint32_t T = 0u;
+    for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t cand = T | (1u << bit);
+        int c = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) c += __popcll(__ballot(key[i] >= cand));
+        if (c >= k) T = cand;
+    }
+    // fewer than k sampled groups (short lists): every real candidate row must pass, the padding
+    // rows (U = -inf) must not
+    if (T == 0u) T = 0x00800000u;                          // ord_key(-FLT_MAX): real rows pass, pads (-inf) do not
+    if (p < nprobe && (lane & 7) == 0) thr[vs] = T;
+    if (lane == 0) cnt_out[(int64_t)q * CNT_STRIDE] = 0;
+}
+
+// sorted_shadow[i] = bf16(bank[sorted_rows[i]]) (zeros for pads)
+__global__ __launch_bounds__(256) void bank_shadow_sorted_kernel(const float* __restrict__ bank,
+                                                                 const int32_t* __restrict__ sorted_rows,
+                                                                 uint16_t* __restrict__ out, int64_t Npad,
+                                                                 int64_t D) {
+    const int64_t per = D / 8;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < Npad * per; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / per, c = i - r * per;
+        const int32_t row = sorted_rows[r];
+        f32x8v x;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = 0.0f;
+        if (row >= 0) {
+            const float4 u = *reinterpret_cast<const float4*>(bank + (int64_t)row * D + 8 * c);
+            const float4 w = *reinterpret_cast<const float4*>(bank + (int64_t)row * D + 8 * c + 4);
+            x[0] = u.x; x[1] = u.y; x[2] = u.z; x[3] = u.w; x[4] = w.x; x[5] = w.y; x[6] = w.z; x[7] = w.w;
+        }
+        *reinterpret_cast<bf16x8v*>(out + r * D + 8 * c) = __builtin_convertvector(x, bf16x8v);
+    }
+}
+
+struct Ivf2Workspace {
+    // shared with the lists / coarse paths
+    float* inv_q; uint32_t* probe; float* probe_dist; int32_t* probe_ids;
+    int32_t* lq_cnt; int32_t* lq_list; int32_t* qbase; int32_t* item_off_old; int32_t* work_counter;
+    int32_t* cnt; float* cand_scores; int32_t* cand_idx;
+    // two-stage inverted lists
+    int32_t* blk_off; int32_t* blk_list; int32_t* blk_row0; int32_t* blk_stride; int32_t* item_off; int32_t* sitem_off; int32_t* nblk;
+    int32_t* slotq; int32_t* qslot; uint32_t* thr; float* gmax; uint16_t* qhat; float4* rowc;
+    int cap; int qp; int64_t bytes;
+};
+
+static Ivf2Workspace carve_ivf2(void* base, int64_t Npad, int64_t nq, int k) {
+    Ivf2Workspace w;
+    char* p = static_cast<char*>(base);
+    int64_t off = 0;
+    auto take = [&](int64_t bytes) {
+        char* r = p ? p + off : nullptr;
+        off += align_up(bytes, 256);
+        return r;
+    };
+    int64_t qp = nq < IVF_MAXQ ? (nq > 0 ? nq : 1) : IVF_MAXQ;
+    w.qp = (int)qp;
+    w.cap = RF_CAP;                                         // refine holds at most this many per query
+    w.inv_q = reinterpret_cast<float*>(take(qp * 4));
+    w.probe = reinterpret_cast<uint32_t*>(take(qp * 32));
+    w.probe_dist = reinterpret_cast<float*>(take(qp * 256 * 4));
+    w.probe_ids = reinterpret_cast<int32_t*>(take(qp * 8 * 4));
+    w.lq_cnt = reinterpret_cast<int32_t*>(take(256 * 4));
+    w.lq_list = reinterpret_cast<int32_t*>(take((int64_t)256 * IVF_MAXQ * 4));
+    w.qbase = reinterpret_cast<int32_t*>(take(qp * 8 * 4));
+    w.item_off_old = reinterpret_cast<int32_t*>(take(257 * 4));
+    w.work_counter = reinterpret_cast<int32_t*>(take(256));
+    w.cnt = reinterpret_cast<int32_t*>(take(qp * CNT_STRIDE * 4));
+    w.cand_scores = reinterpret_cast<float*>(take(qp * w.cap * 4));
+    w.cand_idx = reinterpret_cast<int32_t*>(take(qp * w.cap * 4));
+    w.blk_off = reinterpret_cast<int32_t*>(take(257 * 4));
+    w.blk_list = reinterpret_cast<int32_t*>(take(IVF2_MAXBLK * 4));
+    w.blk_row0 = reinterpret_cast<int32_t*>(take(IVF2_MAXBLK * 4));
+    w.blk_stride = reinterpret_cast<int32_t*>(take(IVF2_MAXBLK * 4));
+    w.item_off = reinterpret_cast<int32_t*>(take((IVF2_MAXBLK + 1) * 4));
+    w.sitem_off = reinterpret_cast<int32_t*>(take((IVF2_MAXBLK + 1) * 4));
+    w.nblk = reinterpret_cast<int32_t*>(take(256));
+    w.slotq = reinterpret_cast<int32_t*>(take((int64_t)IVF2_MAXBLK * 256 * 4));
+    w.qslot = reinterpret_cast<int32_t*>(take(qp * 8 * 4));
+    w.thr = reinterpret_cast<uint32_t*>(take((int64_t)IVF2_MAXBLK * 256 * 4));
+    w.gmax = reinterpret_cast<float*>(take((int64_t)IVF2_MAXBLK * 256 * IVF2_STILES * 4));
+    w.qhat = reinterpret_cast<uint16_t*>(take((int64_t)IVF2_MAXBLK * 256 * 768 * 2));
+    w.rowc = reinterpret_cast<float4*>(take((Npad > 0 ? Npad : 1) * 16));
+    w.bytes = off;
+    return w;
+}
+
+template <int KS>
+inline int launch_coarse_ivf(const CoarseArgs& a, int mode, int grid, hipStream_t s) {
+    const size_t lds = (size_t)CS_SLOTS * (KS * 1024 + CS_AUX_BYTES) + (size_t)CS_BUF * 12 + 256 * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(coarse_scan_kernel<KS, CS_MODE_SAMPLE, true, false, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(coarse_scan_kernel<KS, CS_MODE_FILTER, true, false, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return AURA_E_LAUNCH;
+        attr_set = true;
+    }
+    if (mode == CS_MODE_SAMPLE)
+        hipLaunchKernelGGL((coarse_scan_kernel<KS, CS_MODE_SAMPLE, true, false, true>), dim3(grid), dim3(CS_THREADS), lds, s, a);
+    else
+        hipLaunchKernelGGL((coarse_scan_kernel<KS, CS_MODE_FILTER, true, false, true>), dim3(grid), dim3(CS_THREADS), lds, s, a);
+    return check_launch();
+}

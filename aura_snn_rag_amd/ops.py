@@ -391,6 +391,80 @@ def knn_search_ivf(bank, inv_norm, meta, queries, k: int, now: float, count: int
     return out_s, out_i, ovf
 
 
+def ivf2_layout(list_rows, list_off, list_len):
+    """Padded, list-sorted layout for knn_search_ivf2 from the inverted lists of knn_search_ivf:
+    returns (sorted_rows int32 [n_sorted] with -1 pads, pad_off int32 [257]); every list starts at a
+    multiple of 16."""
+    dev = list_rows.device
+    lens = list_len.to(torch.int64)
+    pad_len = (lens + 15) // 16 * 16
+    pad_off = torch.zeros(257, dtype=torch.int64, device=dev)
+    pad_off[1:] = torch.cumsum(pad_len, 0)
+    n_sorted = max(16, int(pad_off[256].item()))
+    sorted_rows = torch.full((n_sorted,), -1, dtype=torch.int32, device=dev)
+    off = list_off.to(torch.int64)
+    total = int(lens.sum().item())
+    if total:
+        lid = torch.repeat_interleave(torch.arange(256, device=dev), lens)          # list of each listed row
+        src = torch.arange(total, device=dev) + off[0]                               # position in list_rows
+        dst = pad_off[lid] + (src - off[lid])
+        sorted_rows[dst] = list_rows[src]
+    return sorted_rows.contiguous(), pad_off.to(torch.int32).contiguous()
+
+
+def bank_shadow_sorted(bank, sorted_rows) -> torch.Tensor:
+    """bf16 rows in ``sorted_rows`` order (zeros where it is -1)."""
+    _need(bank, "bank", torch.float32); _need(sorted_rows, "sorted_rows", torch.int32)
+    D = bank.shape[1]
+    if D % 8:
+        raise ValueError("bank_shadow_sorted: D % 8 == 0 required")
+    out = torch.empty(sorted_rows.numel(), D, dtype=torch.bfloat16, device=bank.device)
+    check(lib().aura_bank_shadow_sorted(_p(bank), _p(sorted_rows), _p(out), sorted_rows.numel(), D, _stream()),
+          "aura_bank_shadow_sorted")
+    return out
+
+
+def knn_search_ivf2(bank, inv_norm, meta, queries, k: int, now: float, centroids, nprobe: int,
+                    sorted_shadow, sorted_rows, pad_off, list_len, idx_base: int = 0
+                    ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Inverted-list recall through the two-stage scan: (scores [nq, k], idx [nq, k], overflow flag [1]).
+    Same results as ``knn_search_ivf``; ``sorted_*`` / ``pad_off`` from ``ivf2_layout`` +
+    ``bank_shadow_sorted``."""
+    _need(bank, "bank", torch.float32); _need(inv_norm, "inv_norm", torch.float32)
+    _need(meta, "meta", torch.float32); _need(queries, "queries", torch.float32)
+    _need(centroids, "centroids", torch.float32); _need(sorted_shadow, "sorted_shadow", torch.bfloat16)
+    for t, n in ((sorted_rows, "sorted_rows"), (pad_off, "pad_off"), (list_len, "list_len")):
+        _need(t, n, torch.int32)
+    M, D = bank.shape
+    nq = queries.shape[0]
+    n_sorted = sorted_rows.numel()
+    if queries.dim() != 2 or queries.shape[1] != D or meta.shape != (M, 4):
+        raise ValueError("knn_search_ivf2: shape mismatch")
+    if centroids.shape != (256, D) or not (0 < nprobe <= 8):
+        raise ValueError("knn_search_ivf2: centroids must be [256, D], nprobe in [1, 8]")
+    if sorted_shadow.shape != (n_sorted, D) or pad_off.numel() != 257 or list_len.numel() != 256 or n_sorted % 16:
+        raise ValueError("knn_search_ivf2: layout arrays do not match")
+    if not (0 < k <= 256) or D % 8 or D > 768:
+        raise ValueError("knn_search_ivf2: k <= 256, D % 8 == 0, D <= 768")
+    dev = bank.device
+    out_s = torch.empty(nq, k, dtype=torch.float32, device=dev)
+    out_i = torch.empty(nq, k, dtype=torch.int32, device=dev)
+    ovf = torch.zeros(1, dtype=torch.int32, device=dev) if nq == 0 else _ovf_flags.get(dev)
+    if ovf is None:
+        ovf = _ovf_flags[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
+    if nq == 0:
+        return out_s, out_i, ovf
+    L = lib()
+    nbytes = L.aura_knn_ivf2_workspace_bytes(n_sorted, nq, k)
+    ws = _workspace(dev, nbytes)
+    base = (ws.data_ptr() + 255) // 256 * 256
+    check(L.aura_knn_search_ivf2(_p(bank), _p(inv_norm), _p(meta), _p(sorted_shadow), _p(sorted_rows),
+                                 _p(pad_off), _p(list_len), n_sorted, _p(queries), now, D, nq, k,
+                                 _p(centroids), nprobe, idx_base, _p(out_s), _p(out_i), base, nbytes,
+                                 _p(ovf), _stream()), "aura_knn_search_ivf2")
+    return out_s, out_i, ovf
+
+
 def topk_merge(scores, idx, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
     """scores, idx: [S, nq, k] per-shard lists -> merged (scores [nq, k], idx [nq, k])."""
     _need(scores, "scores", torch.float32); _need(idx, "idx", torch.int32)

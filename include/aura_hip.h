@@ -175,7 +175,7 @@ int aura_profile_end(float* ms_out_host, int max_out);
  * the units behind bench.py's algorithmic FLOP count, 2 * rows * nq * D per launch. */
 int aura_profile_last_scan(int64_t* rows_out, int64_t* nq_out);
 /* 0 = the profiled launch was the fp32 matrix scan, 1 = the bf16 prefilter scan over the fp32 bank,
- * 2 = the prefilter scan over the bf16 shadow. */
+ * 2 = the prefilter scan over the bf16 shadow, 3 = the inverted-list prefilter scan (sorted shadow). */
 int aura_profile_last_scan_kind(void);
 
 /* Merge S per-shard top-k lists into the global top-k (the step after the RCCL all-gather,
@@ -218,6 +218,24 @@ int aura_knn_search_shadow(const float* bank, const uint16_t* bank_bf16, const f
                            int64_t nq, int k, int32_t idx_base, float* out_scores, int32_t* out_idx,
                            void* workspace, int64_t workspace_bytes, int flags, int32_t* overflow_out,
                            const float* centroids, int nprobe, void* stream);
+
+/* Centroid-index recall (hippocampal.py:259-270) as inverted lists on the two-stage machinery: the
+ * caller keeps a LIST-SORTED bf16 shadow -- sorted row i holds bf16(bank[sorted_rows[i]]), rows of one
+ * centroid contiguous, every list padded to a multiple of 16 rows (sorted_rows = -1, zeros) -- built
+ * with aura_bank_shadow_sorted whenever the lists change.  pad_off [257] = padded list starts
+ * (pad_off[256] = n_sorted), list_len [256] = real lengths.  Each probed list is streamed once per
+ * batch of up to 2048 queries against the queries that probe it; results (rows, score bits) equal
+ * aura_knn_search_ivf's.  D % 8 == 0, D <= 768, k <= 256, nprobe <= 8; overflow_out as in
+ * aura_knn_search_ex (non-zero: re-run aura_knn_search_ivf or the masked scan). */
+int64_t aura_knn_ivf2_workspace_bytes(int64_t n_sorted, int64_t nq, int k);
+int aura_bank_shadow_sorted(const float* bank, const int32_t* sorted_rows, uint16_t* sorted_bf16,
+                            int64_t n_sorted, int64_t D, void* stream);
+int aura_knn_search_ivf2(const float* bank, const float* inv_norm, const float* meta,
+                         const uint16_t* sorted_bf16, const int32_t* sorted_rows, const int32_t* pad_off,
+                         const int32_t* list_len, int64_t n_sorted, const float* queries, float now,
+                         int64_t D, int64_t nq, int k, const float* centroids, int nprobe,
+                         int32_t idx_base, float* out_scores, int32_t* out_idx, void* workspace,
+                         int64_t workspace_bytes, int32_t* overflow_out, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Surrogate-gradient training path and the prosody-modulated GIF (fp32, [rows][T][H] layout)

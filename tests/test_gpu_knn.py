@@ -491,6 +491,84 @@ def test_bank_shadow_follows_writes(dev):
     same(now)
 
 
+def _lists_of(meta_dev, N):
+    cids = meta_dev[:N, 2].to(torch.int32)
+    order = torch.sort(cids, stable=True).indices.to(torch.int32).contiguous()
+    valid = cids >= 0
+    lens = torch.bincount(cids.clamp(min=0).long(), weights=valid.float(), minlength=256)[:256].to(torch.int32).contiguous()
+    n_neg = (N - valid.sum()).to(torch.int32).reshape(1)
+    off = torch.cat([n_neg, n_neg + torch.cumsum(lens, 0).to(torch.int32)]).contiguous()
+    return order, off, lens
+
+
+@pytest.mark.parametrize("N,D,nq,k,ncent", [(20000, 64, 100, 10, 200), (100000, 768, 256, 32, 256),
+                                            (33333, 200, 1, 5, 256), (50000, 512, 2300, 64, 40),
+                                            (16000, 8, 700, 200, 256)])
+def test_inverted_lists_two_stage(dev, N, D, nq, k, ncent):
+    """Inverted lists on the two-stage scan == the fp32 lists == the masked scan, bit for bit: few
+    centroids (lists probed by > 256 queries -> several blocks per list, > 2048 queries -> several
+    passes), empty lists, rows without a centroid, a query that probes only empty centroids."""
+    from aura_snn_rag_amd import ops
+    g = torch.Generator().manual_seed(N + D + nq)
+    bank = _clustered(N, D, g, n_centres=300, spread=0.4).to(dev).contiguous()
+    inv = torch.empty(N, device=dev); ops.bank_row_norms(bank, inv, 0, N)
+    meta = _meta(N, g, decayed=True, spread_ts=True).to(dev).contiguous()
+    cent = torch.zeros(256, D, device=dev)
+    cent[:ncent] = bank[torch.randint(0, N, (ncent,), generator=g).to(dev)]
+    meta[:, 2] = ops.kmeans_assign(bank, cent, N, ncent).float()
+    meta[::97, 2] = -1.0
+    q = _queries(bank.cpu(), nq, g).to(dev).contiguous()
+    if ncent < 256:
+        q[0] = 0.0                                                  # nearest centroids: the zero rows, no lists
+    order, off, lens = _lists_of(meta, N)
+    srows, pad_off = ops.ivf2_layout(order, off, lens)
+    assert int(pad_off[256]) == srows.numel() and srows.numel() % 16 == 0
+    assert torch.equal(torch.sort(srows[srows >= 0]).values, torch.sort(order[int(off[0]):]).values)
+    sshadow = ops.bank_shadow_sorted(bank, srows)
+    s1, r1, o1 = ops.knn_search_ivf2(bank, inv, meta, q, k, NOW, cent, 8, sshadow, srows, pad_off, lens)
+    flag = int(o1.item())                 # read before the next search resets the shared flag
+    s0, r0 = ops.knn_search(bank, inv, meta, q, k, NOW, centroids=cent, nprobe=8, fp32_scan=True)
+    if flag != 0:
+        # k = 64 over 40 real centroids: a query that probes ONE real list (the rest of its 8 nearest
+        # are the zero centroids) has 32 sample groups for k = 64 -> no bound -> all ~4700 rows of the
+        # list are candidates, more than the refine kernel holds: reported (bit 2), and the queries that
+        # did fit are still exact
+        assert ncent < 256 and flag & 4
+        ok = (r0 == r1).all(1)
+        assert float(ok.float().mean()) > 0.9 and torch.equal(s0[ok], s1[ok])
+        return
+    assert torch.equal(r0, r1) and torch.equal(s0, s1)
+    cap = ops.ivf_capacity(int(torch.topk(lens, 8).values.sum().item()), k)
+    if cap is not None and nq <= 2048:
+        s2, r2, o2 = ops.knn_search_ivf(bank, inv, meta, q, k, NOW, N, cent, 8, order, off, lens, cap)
+        if int(o2.item()) == 0:
+            assert torch.equal(r2, r1) and torch.equal(s2, s1)
+
+
+@pytest.mark.parametrize("k", [100, 200])
+def test_masked_scan_large_k_sparse_candidates(dev, k):
+    """Regression: chunks holding fewer than k candidates (centroid masks, large k).  All masked /
+    padded entries used to share one select key, so "key >= k-th key" matched more than k entries and
+    real candidates were dropped at random; every key is distinct now."""
+    from aura_snn_rag_amd import ops
+    N, D, nq = 16000, 8, 300
+    g = torch.Generator().manual_seed(1)
+    bank = _clustered(N, D, g, n_centres=300, spread=0.4).to(dev).contiguous()
+    inv = torch.empty(N, device=dev); ops.bank_row_norms(bank, inv, 0, N)
+    meta = _meta(N, g, decayed=True, spread_ts=True).to(dev).contiguous()
+    cent = bank[torch.randint(0, N, (256,), generator=g).to(dev)].clone()
+    meta[:, 2] = ops.kmeans_assign(bank, cent, N, 256).float()
+    q = _queries(bank.cpu(), nq, g).to(dev).contiguous()
+    order, off, lens = _lists_of(meta, N)
+    cap = ops.ivf_capacity(int(torch.topk(lens, 8).values.sum().item()), k)
+    sl, rl, _ = ops.knn_search_ivf(bank, inv, meta, q, k, NOW, N, cent, 8, order, off, lens, cap)
+    for fd in (False, True):
+        sm, rm = ops.knn_search(bank, inv, meta, q, k, NOW, centroids=cent, nprobe=8, fp32_scan=True, force_dense=fd)
+        assert torch.equal(rm, rl) and torch.equal(sm, sl)
+    # every query has more candidates than k here, so no -1 may appear
+    assert int((rl < 0).sum()) == 0 or int((rl >= 0).sum(1).min()) >= 1
+
+
 def test_product_centroid_recall_paths_agree(dev):
     """recall_batch with the centroid index on a 10k-row bank: probe masks inside the two-stage scan
     (default, bf16 shadow) == inverted lists (shadow disabled), rows and score bits."""
@@ -513,6 +591,18 @@ def test_product_centroid_recall_paths_agree(dev):
     sa, ra = a.recall_batch(q, k=9, now=now)
     sb, rb = b.recall_batch(q, k=9, now=now)
     assert a._shadow is not None and b._shadow is None
+    assert torch.equal(ra, rb) and torch.equal(sa, sb)
+    # a batch beyond MASKED_SCAN_MAX_QUERIES goes through the inverted lists on the two-stage scan
+    q2 = feats[torch.randint(0, 10000, (700,), generator=g)] + 0.1 * torch.randn(700, D, generator=g)
+    sa, ra = a.recall_batch(q2, k=9, now=now)
+    sb, rb = b.recall_batch(q2, k=9, now=now)
+    assert a._lists2 is not None and b._lists2 is None
+    assert torch.equal(ra, rb) and torch.equal(sa, sb)
+    a.create_episodic_memories([f"n{i}" for i in range(64)], feats[:64] * 1.01)   # lists change
+    b.create_episodic_memories([f"n{i}" for i in range(64)], feats[:64] * 1.01)
+    b.memory_metadata.copy_(a.memory_metadata)
+    sa, ra = a.recall_batch(q2, k=9, now=now)
+    sb, rb = b.recall_batch(q2, k=9, now=now)
     assert torch.equal(ra, rb) and torch.equal(sa, sb)
 
 
