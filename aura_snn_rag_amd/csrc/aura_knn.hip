@@ -2056,7 +2056,7 @@ int aura_knn_search_ivf2(const float* bank, const float* inv_norm, const float* 
         c.N = n_sorted; c.D = D; c.nq = IVF2_MAXBLK * 256;
         c.thr = w.thr; c.cnt = w.cnt; c.cand_scores = w.cand_scores; c.cand_idx = w.cand_idx; c.cap = w.cap;
         c.blk_row0 = w.blk_row0; c.blk_stride = w.blk_stride; c.nblk = w.nblk; c.slotq = w.slotq;
-        c.gmax = w.gmax; c.gmax_ld = IVF2_STILES; c.item_off = w.sitem_off;
+        c.gmax = w.gmax; c.gmax_ld = 2 * IVF2_STILES; c.item_off = w.sitem_off;
         static const int cs_dbg = getenv("AURA_CS_DBG") ? atoi(getenv("AURA_CS_DBG")) : 0;
         c.dbg = cs_dbg;
         auto launch = [&](int mode) -> int {

@@ -624,9 +624,16 @@ __global__ __launch_bounds__(CS_THREADS) void coarse_scan_kernel(const CoarseArg
                 for (int b = 0; b < CS_QB; ++b) {
                     float mx = gm[b];
                     mx = fmaxf(mx, __shfl_xor(mx, 16));
-                    mx = fmaxf(mx, __shfl_xor(mx, 32));
                     const int q = qoff + 16 * b + lr;
-                    if (lg == 0 && q < a.nq) a.gmax[(int64_t)q * a.gmax_ld + (j0 + t)] = mx;   // IVF: tile of the block
+                    if (IVF) {
+                        // inverted lists: 8-row groups (rows 0-7 = lg 0,1; rows 8-15 = lg 2,3), two per
+                        // tile, so that a query probing a single list still has 64 groups for its bound
+                        if ((lg & 1) == 0 && q < a.nq)
+                            a.gmax[(int64_t)q * a.gmax_ld + 2 * (j0 + t) + (lg >> 1)] = mx;
+                    } else {
+                        mx = fmaxf(mx, __shfl_xor(mx, 32));
+                        if (lg == 0 && q < a.nq) a.gmax[(int64_t)q * a.gmax_ld + (j0 + t)] = mx;
+                    }
                 }
             } else if (!(a.dbg & 32)) {
                 // Candidate append, one entry per lane and round: a lane emits its lowest pending

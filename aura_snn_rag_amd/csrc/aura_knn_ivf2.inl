@@ -12,7 +12,7 @@
 //     that probe it).  The block's queries are the scan's stationary bf16 fragments and the list's
 //     contiguous sorted rows stream past them, so a list is read once per batch whatever the batch
 //     size (coarse_scan_kernel<..., IVF>);
-//   * thresholds: a query's T is the k-th largest 16-row group maximum of L over IVF2_STILES tiles
+//   * thresholds: a query's T is the k-th largest 8-row group maximum of L over IVF2_STILES tiles
 //     spread evenly over each of its lists (k distinct candidate rows score >= T; spread because
 //     rows inside a list are in write order and the score has a recency term);
 //   * candidates (U >= T) land in per-query lists with their ORIGINAL row ids and go through
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void ivf2_prep_kernel(const float* __restrict_
 }
 
 // ---- thresholds: one wave per query over the group maxima of its nprobe lists' sample tiles ----
-__global__ __launch_bounds__(256) void ivf2_threshold_kernel(const float* __restrict__ gmax,       // [slots][STILES]
+__global__ __launch_bounds__(256) void ivf2_threshold_kernel(const float* __restrict__ gmax,       // [slots][2 STILES]
                                                              const int32_t* __restrict__ qslot,    // [nq][8]
                                                              const int32_t* __restrict__ blk_list,
                                                              const int32_t* __restrict__ pad_off,
@@ -153,18 +153,19 @@ __global__ __launch_bounds__(256) void ivf2_threshold_kernel(const float* __rest
     const int lane = threadIdx.x & 63;
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= nq) return;
-    // lane -> probe lane>>3, sample tiles 4 (lane&7) .. +3
+    // lane -> probe lane>>3, 8-row sample groups 8 (lane&7) .. +7 (two groups per sample tile)
     const int p = lane >> 3;
-    uint32_t key[4] = {0u, 0u, 0u, 0u};
+    uint32_t key[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
     int vs = -1;
     if (p < nprobe) {
         vs = qslot[(int64_t)q * 8 + p];
         const int list = blk_list[vs >> 8];
         const int tiles = (pad_off[list + 1] - pad_off[list]) / 16;
+        const int groups = 2 * (tiles < IVF2_STILES ? tiles : IVF2_STILES);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int g = 4 * (lane & 7) + i;
-            if (g < tiles && g < IVF2_STILES) key[i] = ord_key(gmax[(int64_t)vs * IVF2_STILES + g]);
+        for (int i = 0; i < 8; ++i) {
+            const int g = 8 * (lane & 7) + i;
+            if (g < groups) key[i] = ord_key(gmax[(int64_t)vs * (2 * IVF2_STILES) + g]);
         }
     }
     uint32_t T = 0u;
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(256) void ivf2_threshold_kernel(const float* __rest
         const uint32_t cand = T | (1u << bit);
         int c = 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) c += __popcll(__ballot(key[i] >= cand));
+        for (int i = 0; i < 8; ++i) c += __popcll(__ballot(key[i] >= cand));
         if (c >= k) T = cand;
     }
     // fewer than k sampled groups (short lists): every real candidate row must pass, the padding
@@ -248,7 +249,7 @@ static Ivf2Workspace carve_ivf2(void* base, int64_t Npad, int64_t nq, int k) {
     w.slotq = reinterpret_cast<int32_t*>(take((int64_t)IVF2_MAXBLK * 256 * 4));
     w.qslot = reinterpret_cast<int32_t*>(take(qp * 8 * 4));
     w.thr = reinterpret_cast<uint32_t*>(take((int64_t)IVF2_MAXBLK * 256 * 4));
-    w.gmax = reinterpret_cast<float*>(take((int64_t)IVF2_MAXBLK * 256 * IVF2_STILES * 4));
+    w.gmax = reinterpret_cast<float*>(take((int64_t)IVF2_MAXBLK * 256 * 2 * IVF2_STILES * 4));
     w.qhat = reinterpret_cast<uint16_t*>(take((int64_t)IVF2_MAXBLK * 256 * 768 * 2));
     w.rowc = reinterpret_cast<float4*>(take((Npad > 0 ? Npad : 1) * 16));
     w.bytes = off;
