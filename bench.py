@@ -218,6 +218,71 @@ def centroid_index_recall(dev, bank, inv, meta, q, k, now, steps=30, shadow=None
                          "avg_kernel_ms": kms, "algorithmic_bytes_per_launch": bytes_alg, "traffic": None}}
 
 
+def centroid_index_1m(dev, k=32, N=1_000_000, D=768, nq=2048, steps=10):
+    """north_star target: >= 1e6 retrievals/s at a 1M x 768 bank on one MI355X.  The reference's
+    centroid-index retrieval (8 nearest of 256 centroids) on a 1M-row bank, 2048-query batches: the
+    inverted lists on the two-stage scan (list-sorted bf16 shadow) next to the fp32 lists; identical
+    results.  HBM roofline of the prefilter launch: every list is streamed once per batch."""
+    from aura_snn_rag_amd import _lib, ops
+    lib = _lib.load()
+    g = torch.Generator(device="cpu").manual_seed(11)
+    bank = torch.empty(N, D, device=dev)
+    for r0 in range(0, N, 1 << 17):
+        bank[r0:r0 + (1 << 17)] = torch.randn(min(1 << 17, N - r0), D, generator=g).to(dev)
+    inv = torch.empty(N, device=dev)
+    ops.bank_row_norms(bank, inv, 0, N)
+    now = 1.7e9
+    meta = torch.zeros(N, 4, device=dev)
+    meta[:, 0] = 1.0; meta[:, 1] = now
+    cent = bank[torch.randperm(N, generator=g)[:256].to(dev)].clone()
+    assign = ops.kmeans_assign(bank, cent, N, 256)
+    ops.kmeans_update(bank, assign, cent, 256, update_means=True)
+    assign = ops.kmeans_assign(bank, cent, N, 256)
+    meta[:, 2] = assign.float()
+    order = torch.sort(assign, stable=True).indices.to(torch.int32).contiguous()
+    lens = torch.bincount(assign.long(), minlength=256)[:256].to(torch.int32).contiguous()
+    off = torch.cat([torch.zeros(1, dtype=torch.int32, device=dev), torch.cumsum(lens, 0).to(torch.int32)]).contiguous()
+    cap = ops.ivf_capacity(int(torch.topk(lens, 8).values.sum().item()), k)
+    srows, pad_off = ops.ivf2_layout(order, off, lens)
+    sshadow = ops.bank_shadow_sorted(bank, srows)
+    q = (bank[torch.randint(0, N, (nq,), generator=g).to(dev)] + 0.5 * torch.randn(nq, D, generator=g).to(dev)).contiguous()
+
+    def two_stage():
+        return ops.knn_search_ivf2(bank, inv, meta, q, k, now, cent, 8, sshadow, srows, pad_off, lens)
+
+    def lists_fp32():
+        return ops.knn_search_ivf(bank, inv, meta, q, k, now, N, cent, 8, order, off, lens, cap)
+    s1, r1, o1 = two_stage()
+    flag = int(o1.item())
+    s0, r0, _ = lists_fp32()
+    same = bool(torch.equal(r0, r1)) and bool(torch.equal(s0, s1)) and flag == 0
+    out = {"bank_rows": N, "dim": D, "queries_per_batch": nq, "k": k, "nprobe": 8, "lists": 256,
+           "identical_results": same}
+    for name, fn in (("two_stage_lists", two_stage), ("fp32_lists", lists_fp32)):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        lib.aura_profile_begin(steps * 2)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        buf = (ctypes.c_float * (steps * 2))()
+        n = lib.aura_profile_end(buf, steps * 2)
+        e = {"retrievals_per_s": nq * steps / dt, "ms_per_batch": dt / steps * 1e3}
+        if name == "two_stage_lists" and n > 0:
+            kms = sum(buf[i] for i in range(n)) / n
+            nbytes = int(srows.numel()) * (D * 2 + 16)
+            e["roofline"] = {"bound": "hbm", "kernel": "coarse_scan_kernel<24,FILTER,bf16 rows,IVF>",
+                             "achieved": nbytes / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": nbytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_kernel_ms": kms,
+                             "algorithmic_bytes_per_launch": nbytes, "traffic": None}
+        out[name] = e
+    del bank, sshadow
+    return out
+
+
 def cpu_baseline(bank_rows, dim, k, nq_sample):
     """The oracle's recall at the REFERENCE's cost model (bank re-normalised per query,
     hippocampal.py:273-279) on the host cores; bit-identical to the reference (tests)."""
@@ -439,6 +504,9 @@ def main():
         out["secondary"] = secondary_neurons(dev)
         out["secondary"]["centroid_index_recall"] = centroid_index_recall(dev, bank, inv, meta, q, k, now,
                                                                           shadow=shadow)
+        del bank, shadow
+        torch.cuda.empty_cache()
+        out["secondary"]["centroid_index_1m"] = centroid_index_1m(dev, k=k)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.bank_rows, D, k, args.cpu_queries)
     if rank == 0:
