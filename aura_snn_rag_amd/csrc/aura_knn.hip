@@ -21,9 +21,11 @@
 // per-query candidate lists; an LDS radix-select + bitonic sort over those lists gives the exact
 // top-k (ties -> lower row).  The result is independent of append order.
 #include <hip/hip_runtime.h>
+#include <cstdio>
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <vector>
 #include <type_traits>
 
 #include "../../include/aura_hip.h"
@@ -2009,12 +2011,14 @@ int aura_bank_shadow_sorted(const float* bank, const int32_t* sorted_rows, uint1
 
 int aura_knn_search_ivf2(const float* bank, const float* inv_norm, const float* meta,
                          const uint16_t* sorted_bf16, const int32_t* sorted_rows, const int32_t* pad_off,
-                         const int32_t* list_len, int64_t n_sorted, const float* queries, float now,
+                         const int32_t* list_len, int64_t n_sorted, int64_t N, const float* queries, float now,
                          int64_t D, int64_t nq, int k,
                          const float* centroids, int nprobe, int32_t idx_base, float* out_scores,
                          int32_t* out_idx, void* workspace, int64_t workspace_bytes,
                          int32_t* overflow_out, void* stream) {
-    if (n_sorted <= 0 || D <= 0 || D > 768 || (D & 7) || nq < 0 || k <= 0 || k > COARSE_MAX_K) return AURA_E_INVAL;
+    if (n_sorted <= 0 || N <= 0 || N > 0x7ffffff0LL || D <= 0 || D > 768 || (D & 7) || nq < 0 || k <= 0 ||
+        k > COARSE_MAX_K)
+        return AURA_E_INVAL;
     if (nprobe <= 0 || nprobe > 8) return AURA_E_INVAL;
     if (nq == 0) return AURA_OK;
     if (!bank || !inv_norm || !meta || !sorted_bf16 || !sorted_rows || !pad_off || !list_len || !queries || !centroids ||
@@ -2032,24 +2036,37 @@ int aura_knn_search_ivf2(const float* bank, const float* inv_norm, const float* 
     const float e_cos = 0.00390625f * (1.0f + 0.001953125f) + 2.0f * (float)D * 5.9604645e-8f + 1e-5f;
     const int cus = device_cu_count();
     int rc;
+    // AURA_IVF2_TRACE: synchronise after every stage and name it on stderr (to localise a device fault)
+    static const bool trace = getenv("AURA_IVF2_TRACE") != nullptr;
+    auto stage = [&](const char* name) {
+        if (trace) {
+            const hipError_t e = hipStreamSynchronize(s);
+            fprintf(stderr, "[ivf2] %s: %s\n", name, e == hipSuccess ? "ok" : hipGetErrorString(e));
+            fflush(stderr);
+        }
+    };
     for (int64_t qb0 = 0; qb0 < nq; qb0 += w.qp) {
         const int nqb = (int)((nq - qb0) < w.qp ? (nq - qb0) : w.qp);
         const float* qptr = queries + qb0 * D;
         if ((rc = launch_probe(centroids, qptr, D, nqb, nprobe, w.probe_dist, w.probe, w.probe_ids, s))) return rc;
+        stage("probe");
         // per-list query lists (the fp32 lists path's preparation; its capacity bookkeeping is unused)
         hipLaunchKernelGGL(ivf_prepare_kernel, dim3(1), dim3(256), 0, s, w.probe_ids, nprobe, nqb,
                            list_len, w.lq_cnt, w.lq_list, w.qbase, w.cnt, w.item_off_old,
                            w.work_counter, 0x7fffffff, 32, nullptr);
         if ((rc = check_launch())) return rc;
+        stage("prepare");
         hipLaunchKernelGGL(ivf2_plan_kernel, dim3(1), dim3(256), 0, s, w.lq_cnt, pad_off, w.blk_off,
                            w.blk_list, w.blk_row0, w.blk_stride, w.item_off, w.sitem_off, w.nblk);
         if ((rc = check_launch())) return rc;
+        stage("plan");
         const int qblocks = IVF2_MAXBLK * 256 / 4;
         hipLaunchKernelGGL(ivf2_prep_kernel, dim3((unsigned)(qblocks + (n_sorted + 255) / 256)), dim3(256), 0, s,
                            qptr, (int64_t)nqb, D, KS, w.lq_cnt, w.lq_list, w.blk_off, w.blk_list, w.nblk, w.qhat,
                            w.inv_q, w.slotq, w.qslot, w.thr, qb0 == 0 ? overflow_out : nullptr, qblocks, meta,
                            inv_norm, sorted_rows, n_sorted, now, e_cos, w.rowc);
         if ((rc = check_launch())) return rc;
+        stage("prep");
 
         CoarseArgs c{};
         c.bank = bank; c.bank16 = sorted_bf16; c.rowc = w.rowc; c.qhat = w.qhat; c.inv_q = w.inv_q;
@@ -2065,24 +2082,51 @@ int aura_knn_search_ivf2(const float* bank, const float* inv_norm, const float* 
             return launch_coarse_ivf<24>(c, mode, cus, s);
         };
         if ((rc = launch(CS_MODE_SAMPLE))) return rc;
+        stage("sample scan");
         hipLaunchKernelGGL(ivf2_threshold_kernel, dim3((unsigned)((nqb + 3) / 4)), dim3(256), 0, s, w.gmax,
                            w.qslot, w.blk_list, pad_off, nprobe, k, nqb, w.thr, w.cnt);
         if ((rc = check_launch())) return rc;
+        stage("threshold");
         c.gmax = nullptr; c.item_off = w.item_off;
         const bool prof = g_prof.on && g_prof.used < g_prof.cap;
         if (prof) {
             (void)hipEventRecord(g_prof.start[g_prof.used], s);
             g_prof.rows = n_sorted; g_prof.nq = nqb; g_prof.kind = 3;
         }
+        if (trace) (void)hipMemsetAsync(w.cand_idx, 0xff, (size_t)nqb * w.cap * 4, s);   // unwritten slots show up as row -1
         if ((rc = launch(CS_MODE_FILTER))) return rc;
         if (prof) (void)hipEventRecord(g_prof.stop[g_prof.used++], s);
+        stage("filter scan");
 
         RefineArgs r{};
         r.bank = bank; r.inv_norm = inv_norm; r.meta = meta; r.queries = qptr; r.inv_q = w.inv_q;
-        r.now = now; r.e_cos = e_cos; r.N = 0; r.D = D; r.k = k; r.cnt = w.cnt;
+        r.now = now; r.e_cos = e_cos; r.N = N; r.D = D; r.k = k; r.cnt = w.cnt;
         r.cand_scores = w.cand_scores; r.cand_idx = w.cand_idx; r.cap = w.cap; r.idx_base = idx_base;
         r.out_scores = out_scores + qb0 * k; r.out_idx = out_idx + qb0 * k; r.overflow = overflow_out;
+        if (trace) {                                         // candidate lists with row ids outside the bank
+            (void)hipStreamSynchronize(s);
+            std::vector<int32_t> hc((size_t)nqb * CNT_STRIDE), hi((size_t)nqb * w.cap);
+            std::vector<float> hu((size_t)nqb * w.cap);
+            (void)hipMemcpy(hc.data(), w.cnt, hc.size() * 4, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(hi.data(), w.cand_idx, hi.size() * 4, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(hu.data(), w.cand_scores, hu.size() * 4, hipMemcpyDeviceToHost);
+            int shown = 0; long bad = 0, tot = 0;
+            for (int q = 0; q < nqb; ++q) {
+                const int n = hc[(size_t)q * CNT_STRIDE] < w.cap ? hc[(size_t)q * CNT_STRIDE] : w.cap;
+                tot += n;
+                for (int i = 0; i < n; ++i) {
+                    const int32_t row = hi[(size_t)q * w.cap + i];
+                    if ((uint32_t)row < (uint32_t)N) continue;
+                    ++bad;
+                    if (shown++ < 40)
+                        fprintf(stderr, "[ivf2] invalid candidate: q %d pos %d of %d row %d (0x%08x) U %g\n", q, i, n,
+                                row, (unsigned)row, hu[(size_t)q * w.cap + i]);
+                }
+            }
+            fprintf(stderr, "[ivf2] candidates %ld, invalid %ld\n", tot, bad);
+        }
         if ((rc = launch_refine_for(r, nqb, D, cus, s))) return rc;
+        stage("refine");
     }
     return AURA_OK;
 }

@@ -742,8 +742,12 @@ __global__ __launch_bounds__(RF_THREADS) void coarse_refine_kernel(const RefineA
     if (n > capn) { ovf = true; ovf_bits |= 4; n = capn; }
 
     for (int i = tid; i < n; i += RF_THREADS) {
-        const float u = a.cand_scores[(int64_t)q * a.cap + i];
-        const int32_t r = a.cand_idx[(int64_t)q * a.cap + i];
+        float u = a.cand_scores[(int64_t)q * a.cap + i];
+        int32_t r = a.cand_idx[(int64_t)q * a.cap + i];
+        if ((uint32_t)r >= (uint32_t)a.N) {              // never a valid row: fail loudly (bit 4), do not fault
+            if (a.overflow) atomicOr(a.overflow, 16);
+            r = 0; u = -INFINITY;
+        }
         const float err = 0.5f * a.e_cos * fabsf(a.meta[(int64_t)r * 4]);
         s_u[i] = u;
         s_i[i] = r;

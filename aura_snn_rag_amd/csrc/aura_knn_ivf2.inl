@@ -178,7 +178,9 @@ __global__ __launch_bounds__(256) void ivf2_threshold_kernel(const float* __rest
     }
     // fewer than k sampled groups (short lists): every real candidate row must pass, the padding
     // rows (U = -inf) must not
-    if (T == 0u) T = 0x00800000u;                          // ord_key(-FLT_MAX): real rows pass, pads (-inf) do not
+    // ... and a k-th largest maximum that belongs to a pad-only group (-inf) must not become the bound
+    // either: "U >= -inf" would admit the padding rows, whose row id is -1
+    if (T < 0x00800000u) T = 0x00800000u;                  // ord_key(-FLT_MAX): real rows pass, pads (-inf) do not
     if (p < nprobe && (lane & 7) == 0) thr[vs] = T;
     if (lane == 0) cnt_out[(int64_t)q * CNT_STRIDE] = 0;
 }

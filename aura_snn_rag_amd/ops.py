@@ -459,7 +459,7 @@ def knn_search_ivf2(bank, inv_norm, meta, queries, k: int, now: float, centroids
     ws = _workspace(dev, nbytes)
     base = (ws.data_ptr() + 255) // 256 * 256
     check(L.aura_knn_search_ivf2(_p(bank), _p(inv_norm), _p(meta), _p(sorted_shadow), _p(sorted_rows),
-                                 _p(pad_off), _p(list_len), n_sorted, _p(queries), now, D, nq, k,
+                                 _p(pad_off), _p(list_len), n_sorted, M, _p(queries), now, D, nq, k,
                                  _p(centroids), nprobe, idx_base, _p(out_s), _p(out_i), base, nbytes,
                                  _p(ovf), _stream()), "aura_knn_search_ivf2")
     return out_s, out_i, ovf

@@ -130,8 +130,10 @@ int aura_knn_search(const float* bank, const float* inv_norm, const float* meta,
  * the caller falls back to the full scan, :269-270); flags (AURA_KNN_FORCE_DENSE scores every row densely instead
  * of using the sampled-threshold filter; same results, used by tests) and overflow_out (device
  * int32, reset by every call and set non-zero if a candidate list overflowed -- bit 0: filter
- * list of the fp32 scan, bit 2 / bit 3: candidate / survivor list of the two-stage path -- the
- * caller must then re-run with AURA_KNN_FORCE_DENSE; may be NULL). */
+ * list of the fp32 scan, bit 2 / bit 3: candidate / survivor list of the two-stage path, bit 4: a
+ * candidate row id outside [0, N) reached the re-scoring stage (an internal invariant broke; the row
+ * is dropped instead of dereferenced) -- the caller must then re-run with AURA_KNN_FORCE_DENSE; may
+ * be NULL). */
 #define AURA_KNN_FORCE_DENSE 1
 /* AURA_KNN_FP32_SCAN: score every row on the fp32 matrix pipe.  Without it, large banks
  * (>= 8192 rows, D <= 768, D % 4 == 0, no location term / centroid mask, k <= 256) are first
@@ -225,14 +227,15 @@ int aura_knn_search_shadow(const float* bank, const uint16_t* bank_bf16, const f
  * with aura_bank_shadow_sorted whenever the lists change.  pad_off [257] = padded list starts
  * (pad_off[256] = n_sorted), list_len [256] = real lengths.  Each probed list is streamed once per
  * batch of up to 2048 queries against the queries that probe it; results (rows, score bits) equal
- * aura_knn_search_ivf's.  D % 8 == 0, D <= 768, k <= 256, nprobe <= 8; overflow_out as in
+ * aura_knn_search_ivf's.  N = rows of the bank (every sorted_rows entry is < N).  D % 8 == 0,
+ * D <= 768, k <= 256, nprobe <= 8; overflow_out as in
  * aura_knn_search_ex (non-zero: re-run aura_knn_search_ivf or the masked scan). */
 int64_t aura_knn_ivf2_workspace_bytes(int64_t n_sorted, int64_t nq, int k);
 int aura_bank_shadow_sorted(const float* bank, const int32_t* sorted_rows, uint16_t* sorted_bf16,
                             int64_t n_sorted, int64_t D, void* stream);
 int aura_knn_search_ivf2(const float* bank, const float* inv_norm, const float* meta,
                          const uint16_t* sorted_bf16, const int32_t* sorted_rows, const int32_t* pad_off,
-                         const int32_t* list_len, int64_t n_sorted, const float* queries, float now,
+                         const int32_t* list_len, int64_t n_sorted, int64_t N, const float* queries, float now,
                          int64_t D, int64_t nq, int k, const float* centroids, int nprobe,
                          int32_t idx_base, float* out_scores, int32_t* out_idx, void* workspace,
                          int64_t workspace_bytes, int32_t* overflow_out, void* stream);

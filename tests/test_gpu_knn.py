@@ -450,6 +450,13 @@ def test_two_stage_random_sweep(dev):
     assert sweep(cases=16, seed=2026, dev=dev, verbose=False) == 0
 
 
+def test_inverted_lists_random_sweep(dev):
+    """12 random (N, D, nq, k, centroid count, metadata) cases of the inverted lists on the two-stage scan
+    against the masked fp32 scan (tools/ivf2_fuzz.py runs longer sweeps)."""
+    from tools.ivf2_fuzz import sweep
+    assert sweep(cases=12, seed=77, dev=dev, verbose=False) == 0
+
+
 def test_bank_shadow_follows_writes(dev):
     """HippocampalFormation keeps the bf16 shadow current across appends, ring overwrites and
     state_dict loads: recall is bit-identical to a bank that never uses the shadow."""
