@@ -13,7 +13,8 @@ from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
 from typing import Optional
 
 LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib")
-LIB_PATH = os.path.join(LIB_DIR, "libaura_hip.so")
+# AURA_HIP_LIB: another build of the same library (kernel tuning experiments, tools/variant_sweep.sh)
+LIB_PATH = os.environ.get("AURA_HIP_LIB") or os.path.join(LIB_DIR, "libaura_hip.so")
 
 AURA_OK = 0
 ERRORS = {-1: "AURA_E_INVAL (bad argument)", -2: "AURA_E_LAUNCH (HIP launch error)",

@@ -106,6 +106,10 @@ __device__ __forceinline__ void glds4(const float* g, char* lds_wave_base) {
 // the 384 registers of query fragments are pinned by hand: the first CS_QA fragments live in
 // AGPRs (the hardware reads srcB from either file), the rest in VGPRs.  Hazards the compiler
 // would cover for its own MFMAs are covered by the s_nop statements around the groups.
+#ifndef AURA_CS_PF16
+#define AURA_CS_PF16 4
+#endif
+constexpr int CS_PF16 = AURA_CS_PF16;       // bf16-row kernels: fragment reads run this many k-steps ahead
 constexpr int CS_QA = 60;   // fragments (4 registers each) kept in AGPRs, next to the 16 accumulators
 // LDS accesses of the steady-state loop that are NOT the MFMA fragments go through inline asm:
 // hipcc puts "s_waitcnt vmcnt(0)" in front of an ordinary LDS access it cannot separate from an
@@ -161,16 +165,27 @@ __device__ __forceinline__ void mfma_bf16_q(f32x4v& acc, const bf16x8v& af, cons
     // it; they elapse while the previous MFMA still occupies the pipe.
     // LAST (the tile's final k-step): 12 wait states behind the MFMA, INSIDE the statement, because
     // the compiler may read or move the accumulator right after it (it has no idea this is an MFMA).
+    // AURA_CS_EXP_*: timing experiments only (tools/build_variant.sh; results are wrong with them)
+#ifdef AURA_CS_EXP_NONOP
+#define AURA_NOP1 ""
+#else
+#define AURA_NOP1 "s_nop 1\n\t"
+#endif
+#ifdef AURA_CS_EXP_NOMFMA
+#define AURA_MFMA "; "
+#else
+#define AURA_MFMA "v_mfma_f32_16x16x32_bf16 "
+#endif
     if constexpr (QA && LAST)
-        asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\ts_nop 7\n\ts_nop 4"
+        asm volatile(AURA_NOP1 AURA_MFMA "%0, %1, %2, %0\n\ts_nop 7\n\ts_nop 4"
                      : "+a"(acc) : "v"(af), "a"(q));
     else if constexpr (QA)
-        asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(af), "a"(q));
+        asm volatile(AURA_NOP1 AURA_MFMA "%0, %1, %2, %0" : "+a"(acc) : "v"(af), "a"(q));
     else if constexpr (LAST)
-        asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\ts_nop 7\n\ts_nop 4"
+        asm volatile(AURA_NOP1 AURA_MFMA "%0, %1, %2, %0\n\ts_nop 7\n\ts_nop 4"
                      : "+a"(acc) : "v"(af), "v"(q));
     else
-        asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(af), "v"(q));
+        asm volatile(AURA_NOP1 AURA_MFMA "%0, %1, %2, %0" : "+a"(acc) : "v"(af), "v"(q));
 }
 
 // Per-call preparation for the two-stage path, one launch:
@@ -506,25 +521,30 @@ __global__ __launch_bounds__(CS_THREADS) void coarse_scan_kernel(const CoarseArg
             f32x4v rcv[4];                                   // constants of rows 4 lg .. 4 lg + 3
             // fragment reads run two k-steps ahead of the MFMAs (one wave per SIMD: nothing else
             // hides the LDS latency)
-            f32x4v xr[3][2];
+            constexpr int PF = SRC16 ? CS_PF16 : 2;         // k-steps the reads run ahead
+            f32x4v xr[PF + 1][2];
             if (!(a.dbg & 1)) {
 #pragma unroll
-            for (int s = 0; s < 2 && s < KS; ++s) {
+            for (int s = 0; s < PF && s < KS; ++s) {
                 xr[s][0] = *reinterpret_cast<const f32x4v*>(sb + s * STEP_BYTES + off0);
                 if (!SRC16) xr[s][1] = *reinterpret_cast<const f32x4v*>(sb + s * STEP_BYTES + off1);
             }
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                if (s + 2 < KS) {
-                    xr[(s + 2) % 3][0] = *reinterpret_cast<const f32x4v*>(sb + (s + 2) * STEP_BYTES + off0);
+#ifdef AURA_CS_EXP_NOREAD
+                if (false) {
+#else
+                if (s + PF < KS) {
+#endif
+                    xr[(s + PF) % (PF + 1)][0] = *reinterpret_cast<const f32x4v*>(sb + (s + PF) * STEP_BYTES + off0);
                     if (!SRC16)
-                        xr[(s + 2) % 3][1] = *reinterpret_cast<const f32x4v*>(sb + (s + 2) * STEP_BYTES + off1);
+                        xr[(s + PF) % (PF + 1)][1] = *reinterpret_cast<const f32x4v*>(sb + (s + PF) * STEP_BYTES + off1);
                 }
                 bf16x8v af;
                 if (SRC16) {
-                    af = __builtin_bit_cast(bf16x8v, xr[s % 3][0]);
+                    af = __builtin_bit_cast(bf16x8v, xr[s % (PF + 1)][0]);
                 } else {
-                    const f32x4v x0 = xr[s % 3][0], x1 = xr[s % 3][1];
+                    const f32x4v x0 = xr[s % (PF + 1)][0], x1 = xr[s % (PF + 1)][1];
                     f32x8v x;
                     x[0] = x0[0]; x[1] = x0[1]; x[2] = x0[2]; x[3] = x0[3];
                     x[4] = x1[0]; x[5] = x1[1]; x[6] = x1[2]; x[7] = x1[3];
