@@ -1717,6 +1717,12 @@ inline int run_coarse_pass(const float* bank, const uint16_t* bank16, const floa
     if ((rc = check_launch())) return rc;
 
     c.n_tiles = (N + CS_ROWS - 1) / CS_ROWS; c.gmax = nullptr;
+    static int tm_left = 3;                                  // AURA_CS_DBG bit 64: phase times of the first launches
+    const bool tm = (cs_dbg & 64) && tm_left > 0;
+    if (tm) {
+        c.gmax = w.gmax;
+        (void)hipMemsetAsync(w.gmax, 0, (size_t)cus * 8 * 8 * 4, s);
+    }
     const bool prof = g_prof.on && g_prof.used < g_prof.cap;
     if (prof) {
         (void)hipEventRecord(g_prof.start[g_prof.used], s);
@@ -1727,6 +1733,31 @@ inline int run_coarse_pass(const float* bank, const uint16_t* bank16, const floa
         if ((rc = dispatch_coarse(c, CS_MODE_FILTER, (int)(items < cus ? items : cus), s))) return rc;
     }
     if (prof) (void)hipEventRecord(g_prof.stop[g_prof.used++], s);
+    if (tm) {
+        --tm_left;
+        (void)hipStreamSynchronize(s);
+        std::vector<float> h((size_t)cus * 64);
+        (void)hipMemcpy(h.data(), w.gmax, h.size() * 4, hipMemcpyDeviceToHost);
+        static const char* const names[6] = {"wait+barrier", "check+issue", "-", "mfma loop", "write-out", "epilogue"};
+        for (int role = 0; role < 2; ++role) {
+            double sum[6] = {0, 0, 0, 0, 0, 0}, tiles = 0; int waves = 0;
+            for (int g = 0; g < cus; ++g)
+                for (int wv = role * 4; wv < role * 4 + 4; ++wv) {
+                    const float* o = &h[((size_t)g * 8 + wv) * 8];
+                    if (o[6] <= 0) continue;
+                    for (int i = 0; i < 6; ++i) sum[i] += o[i];
+                    tiles += o[6]; ++waves;
+                }
+            if (!waves) continue;
+            fprintf(stderr, "[cs phases] waves %d-%d: %d waves, %.1f tiles each;", role * 4, role * 4 + 3, waves, tiles / waves);
+            double tot = 0;
+            for (int i = 0; i < 6; ++i) {
+                fprintf(stderr, " %s %.2f us (%.0f ns/tile);", names[i], sum[i] / waves * 0.01, sum[i] / tiles * 10.0);
+                tot += sum[i];
+            }
+            fprintf(stderr, " total %.2f us\n", tot / waves * 0.01);
+        }
+    }
 
     RefineArgs r{};
     r.bank = bank; r.inv_norm = inv_norm; r.meta = meta; r.queries = qptr; r.inv_q = w.inv_q;
@@ -2076,10 +2107,16 @@ int aura_knn_search_ivf2(const float* bank, const float* inv_norm, const float* 
         c.gmax = w.gmax; c.gmax_ld = 2 * IVF2_STILES; c.item_off = w.sitem_off;
         static const int cs_dbg = getenv("AURA_CS_DBG") ? atoi(getenv("AURA_CS_DBG")) : 0;
         c.dbg = cs_dbg;
+        static const bool w4 = getenv("AURA_CS_WAVES4") != nullptr;   // A/B runs: one wave per SIMD
         auto launch = [&](int mode) -> int {
-            if (KS == 8) return launch_coarse_ivf<8>(c, mode, cus, s);
-            if (KS == 16) return launch_coarse_ivf<16>(c, mode, cus, s);
-            return launch_coarse_ivf<24>(c, mode, cus, s);
+            if (w4) {
+                if (KS == 8) return launch_coarse_ivf<8, 4>(c, mode, cus, s);
+                if (KS == 16) return launch_coarse_ivf<16, 4>(c, mode, cus, s);
+                return launch_coarse_ivf<24, 4>(c, mode, cus, s);
+            }
+            if (KS == 8) return launch_coarse_ivf<8, 8>(c, mode, cus, s);
+            if (KS == 16) return launch_coarse_ivf<16, 8>(c, mode, cus, s);
+            return launch_coarse_ivf<24, 8>(c, mode, cus, s);
         };
         if ((rc = launch(CS_MODE_SAMPLE))) return rc;
         stage("sample scan");

@@ -110,6 +110,7 @@ __device__ __forceinline__ void glds4(const float* g, char* lds_wave_base) {
 #define AURA_CS_PF16 4
 #endif
 constexpr int CS_PF16 = AURA_CS_PF16;       // bf16-row kernels: fragment reads run this many k-steps ahead
+constexpr int CS_QA8 = 30;  // 8-wave kernels (48 fragments, 8 accumulators per wave)
 constexpr int CS_QA = 60;   // fragments (4 registers each) kept in AGPRs, next to the 16 accumulators
 // LDS accesses of the steady-state loop that are NOT the MFMA fragments go through inline asm:
 // hipcc puts "s_waitcnt vmcnt(0)" in front of an ordinary LDS access it cannot separate from an
@@ -156,6 +157,30 @@ __device__ __forceinline__ int lds_read_i32(uint32_t addr) {
 __device__ __forceinline__ void lds_write3(uint32_t addr, uint32_t a0, uint32_t a1, uint32_t a2) {
     asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %0, %2 offset:4\n\tds_write_b32 %0, %3 offset:8"
                  :: "v"(addr), "v"(a0), "v"(a1), "v"(a2) : "memory");
+}
+
+// XOR swizzles of the tile image (chunk slot = chunk ^ swz(row)), chosen for the lane groups in which
+// gfx950 services a wave's ds_read_b128 -- {0-3,12-15,20-27}, {4-11,16-19,28-31}, {32-35,44-47,52-59},
+// {36-43,48-51,60-63} (MI355X_MICROARCH.md, LDS table), NOT four runs of 16 consecutive lanes: with the
+// MFMA A layout (lane -> row lane&15, k-group lane>>4) a group holds rows 0-3 and 12-15 of one k-group
+// and rows 4-11 of the next, and all 16 lanes must land in different 16-byte bank quads.
+//   bf16 image, 4 chunks per row : swz = (4 - row/4) & 3          = 0,3,2,1 for rows 0-3,4-7,8-11,12-15
+//   fp32 image, 8 chunks per row : swz = (m & 1) | (m & 4 ? 6 : 0), m = row/2   = 0,1,0,1,6,7,6,7
+// (AURA_CS_EXP_OLDSWZ: the first version's row/4 and row/2, conflict-free only for consecutive lanes.)
+__device__ __forceinline__ uint32_t cs_swz16(uint32_t row) {
+#ifdef AURA_CS_EXP_OLDSWZ
+    return (row >> 2) & 3;
+#else
+    return (4u - (row >> 2)) & 3u;
+#endif
+}
+__device__ __forceinline__ uint32_t cs_swz32(uint32_t row) {
+#ifdef AURA_CS_EXP_OLDSWZ
+    return (row >> 1) & 7;
+#else
+    const uint32_t m = row >> 1;
+    return (m & 1u) | ((m & 4u) ? 6u : 0u);
+#endif
 }
 
 template <bool QA, bool LAST>
@@ -289,16 +314,23 @@ __global__ __launch_bounds__(256) void coarse_threshold_kernel(const float* __re
 // MASKED = centroid-candidate mode: the 256 queries' probe masks (8 KB) sit in LDS behind the candidate
 // buffer (only the bf16-row variant has the room) and gate every (query, row) pair in the epilogue.
 // IVF = inverted-list mode (see CoarseArgs): same scan, the work items are (block, tile) pairs.
-template <int KS, int MODE, bool SRC16, bool MASKED, bool IVF = false>
-__global__ __launch_bounds__(CS_THREADS) void coarse_scan_kernel(const CoarseArgs a) {
+// NW = waves per workgroup: 4 (one per SIMD, 64 queries and 512 registers each) or, bf16 rows only,
+// 8 (two per SIMD, 32 queries and 256 registers each: the second wave fills the first one's stalls).
+template <int KS, int MODE, bool SRC16, bool MASKED, bool IVF = false, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a) {
     static_assert(!MASKED || SRC16, "the probe masks need the LDS the bf16 rows leave free");
     static_assert(!IVF || (SRC16 && !MASKED), "inverted lists run over the sorted bf16 shadow");
-    static_assert(KS % 4 == 0, "pieces are dealt over 4 waves");
+    static_assert(NW == 4 || (NW == 8 && SRC16), "8 waves: bf16 rows only");
+    static_assert(KS % NW == 0, "pieces are dealt over the waves");
+    constexpr int THREADS = 64 * NW;
+    constexpr int QB = 16 / NW;                            // 16-query MFMA column blocks per wave
+    constexpr int QA = NW == 4 ? CS_QA : CS_QA8;           // fragments pinned in AGPRs
     constexpr int STEP_BYTES = SRC16 ? 1024 : 2048;        // one k-step (32 k) of 16 rows
     constexpr int TILE_BYTES = KS * STEP_BYTES;
     constexpr int SLOT_BYTES = TILE_BYTES + CS_AUX_BYTES;
-    constexpr int NP = SRC16 ? KS / 4 : KS / 2;            // bank pieces (1 KiB each) per wave and tile
+    constexpr int NP = SRC16 ? KS / NW : KS / 2;           // bank pieces (1 KiB each) per wave and tile
     constexpr int GL = NP + 1;                             // global_load_lds per wave and tile
+    constexpr int NSLOT = CS_SLOTS;                        // ring slots
     extern __shared__ __attribute__((aligned(16))) char csmem[];
     // candidate buffer [2][CS_BUF/2][3] follows the slots (addressed through buf_addr)
     __shared__ int s_nb[2];
@@ -320,7 +352,7 @@ __global__ __launch_bounds__(CS_THREADS) void coarse_scan_kernel(const CoarseArg
     // lanes of a ds_read_b128 phase hit 16 different bank quads:
     //   fp32 image: 8 chunks of 16 B per row (128 B); the lane reads chunks 2 lg and 2 lg + 1
     //   bf16 image: 4 chunks of 16 B per row ( 64 B); the lane reads chunk lg
-    const int sw = SRC16 ? (lr >> 2) & 3 : (lr >> 1) & 7;
+    const int sw = SRC16 ? cs_swz16(lr) : cs_swz32(lr);
     const int off0 = SRC16 ? (4 * lr + (lg ^ sw)) * 16 : (8 * lr + ((2 * lg) ^ sw)) * 16;
     const int off1 = SRC16 ? 0 : (8 * lr + ((2 * lg + 1) ^ sw)) * 16;
     // Loader roles.  The image is swizzled by choosing WHICH 16-byte chunk a lane fetches (LDS-DMA
@@ -331,11 +363,8 @@ __global__ __launch_bounds__(CS_THREADS) void coarse_scan_kernel(const CoarseArg
     //         8 half + lane/8, chunk (lane&7) ^ swizzle of the 128-byte line
     //   bf16: piece m = wave + 4 i -> k-step m; lane -> row lane/4, chunk (lane&3) ^ swizzle of the
     //         64-byte half line
-    const uint32_t ld_rho = SRC16 ? (uint32_t)(lane >> 2) : 8 * (wave & 1) + (lane >> 3);
-    const uint32_t ld_cch = SRC16 ? (lane & 3) ^ ((ld_rho >> 2) & 3) : (lane & 7) ^ ((ld_rho >> 1) & 7);
     constexpr uint32_t ESZ = SRC16 ? 2 : 4, ECH = SRC16 ? 8 : 4;    // element bytes, elements per chunk
-    const uint32_t ld_kf0 = (SRC16 ? 32 * wave : 32 * (wave >> 1)) + ECH * ld_cch;   // elements; piece i: + 256 B
-    const uint32_t voff0 = (ld_rho * D + ld_kf0) * ESZ;             // bytes from the tile's first row
+    constexpr int PSTEP = SRC16 ? 64 * NW : 256;           // bytes between a wave's pieces inside a row
     const bool full_k = D == (uint32_t)(KS * 32);
     const char* const src = SRC16 ? reinterpret_cast<const char*>(a.bank16) : reinterpret_cast<const char*>(a.bank);
 
@@ -349,6 +378,15 @@ __global__ __launch_bounds__(CS_THREADS) void coarse_scan_kernel(const CoarseArg
     auto issue = [&](int64_t j, int slot) {
         char* const sb = csmem + slot * SLOT_BYTES +
                          (SRC16 ? wave * 1024 : (wave & 1) * 1024 + (wave >> 1) * 2048);
+        // 8-wave kernels recompute the lane's loader role per call (256 registers per wave: values kept
+        // live across the fragment loads get spilled, and a scratch reload waits for vmcnt(0), which
+        // drains the prefetch)
+        uint32_t ln = (uint32_t)lane;
+        if (NW == 8) asm volatile("" : "+v"(ln));
+        const uint32_t ld_rho = SRC16 ? ln >> 2 : 8 * (wave & 1) + (ln >> 3);
+        const uint32_t ld_cch = SRC16 ? (ln & 3) ^ cs_swz16(ld_rho) : (ln & 7) ^ cs_swz32(ld_rho);
+        const uint32_t ld_kf0 = (SRC16 ? 32 * wave : 32 * (wave >> 1)) + ECH * ld_cch;   // elements; piece i: + PSTEP B
+        const uint32_t voff0 = (ld_rho * D + ld_kf0) * ESZ;             // bytes from the tile's first row
         const int64_t r0 = tile_row0(j);
         const char* base = src + r0 * (int64_t)D * ESZ;
         if (r0 + CS_ROWS > a.N) {                          // last, partial tile: clamp the row
@@ -358,15 +396,15 @@ __global__ __launch_bounds__(CS_THREADS) void coarse_scan_kernel(const CoarseArg
         if (full_k) {
 #pragma unroll
             for (int i = 0; i < NP; ++i)
-                glds16(reinterpret_cast<const float*>(base + voff0 + 256 * i), sb + i * 4096);
+                glds16(reinterpret_cast<const float*>(base + voff0 + PSTEP * i), sb + i * (1024 * NW));
         } else {
             uint32_t kf0 = ld_kf0;
             asm volatile("" : "+v"(kf0));                  // recompute per call: hoisting these
 #pragma unroll                                             // addresses out of the tile loop spills
             for (int i = 0; i < NP; ++i) {
-                uint32_t kf = kf0 + (256 / ESZ) * i;
+                uint32_t kf = kf0 + (PSTEP / ESZ) * i;
                 if (kf >= D) kf = D - ECH;
-                glds16(reinterpret_cast<const float*>(base + (ld_rho * D + kf) * ESZ), sb + i * 4096);
+                glds16(reinterpret_cast<const float*>(base + (ld_rho * D + kf) * ESZ), sb + i * (1024 * NW));
             }
         }
         {   // row constants (every wave issues the same piece: uniform vmcnt, same bytes)
@@ -380,18 +418,19 @@ __global__ __launch_bounds__(CS_THREADS) void coarse_scan_kernel(const CoarseArg
     // tile t and can be inspected / flushed without any extra barrier
     constexpr int HALF = CS_BUF / 2;
     const uint32_t nb_addr = lds_addr(s_nb), cs_base = lds_addr(csmem);
-    const uint32_t buf_addr = cs_base + CS_SLOTS * SLOT_BYTES;
+    const uint32_t buf_addr = cs_base + NSLOT * SLOT_BYTES;
     const uint32_t mask_addr = buf_addr + CS_BUF * 12;            // [256][8] probe masks (MASKED) / [256] slot -> query (IVF)
     // span-end write-out of both halves: every slot reservation is issued before any is waited for
     // (up to 4 entries per thread), then one wait, then the stores
     auto flush_all = [&](int n0, int n1) {
         n0 = n0 < HALF ? n0 : HALF;
         n1 = n1 < HALF ? n1 : HALF;
-        int pos[4];
+        constexpr int EPT = HALF / THREADS;               // entries per thread and half
+        int pos[4] = {-1, -1, -1, -1};
         uint32_t eq[4], er[4], eu[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = tid + (u & 1) * CS_THREADS, h = u >> 1;
+        for (int u = 0; u < 2 * EPT; ++u) {
+            const int i = tid + (u % EPT) * THREADS, h = u / EPT;
             pos[u] = -1;
             if (i < (h ? n1 : n0)) {
                 lds_read3(buf_addr + (h * HALF + i) * 12, eq[u], er[u], eu[u]);
@@ -400,8 +439,8 @@ __global__ __launch_bounds__(CS_THREADS) void coarse_scan_kernel(const CoarseArg
         }
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(pos[0]), "+v"(pos[1]), "+v"(pos[2]), "+v"(pos[3])::"memory");
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = tid + (u & 1) * CS_THREADS, h = u >> 1;
+        for (int u = 0; u < 2 * EPT; ++u) {
+            const int i = tid + (u % EPT) * THREADS, h = u / EPT;
             if (i < (h ? n1 : n0) && pos[u] < a.cap) {
                 a.cand_scores[(int64_t)eq[u] * a.cap + pos[u]] = __uint_as_float(eu[u]);
                 a.cand_idx[(int64_t)eq[u] * a.cap + pos[u]] = (int32_t)er[u];
@@ -430,42 +469,42 @@ __global__ __launch_bounds__(CS_THREADS) void coarse_scan_kernel(const CoarseArg
             seg = (hi - c) < (a.n_tiles - j0) ? (hi - c) : (a.n_tiles - j0);
         }
         c += seg;
-        const int qoff = (int)qblk * 256 + wave * 64;      // this wave's first query (IVF: block slot)
+        const int qoff = (int)qblk * 256 + wave * (16 * QB);   // this wave's first query (IVF: block slot)
         if (IVF && MODE == CS_MODE_FILTER) {                // slot -> query table of this block -> LDS
-            int32_t* const s_sq = reinterpret_cast<int32_t*>(csmem + CS_SLOTS * SLOT_BYTES + CS_BUF * 12);
-            s_sq[tid] = a.slotq[qblk * 256 + tid];          // CS_THREADS == 256
+            int32_t* const s_sq = reinterpret_cast<int32_t*>(csmem + NSLOT * SLOT_BYTES + CS_BUF * 12);
+            if (tid < 256) s_sq[tid] = a.slotq[qblk * 256 + tid];
             __syncthreads();
         }
 
         // ---- stationary operand: 64 (normalised) queries of this wave as bf16 B-fragments ----
         // one coalesced 16-byte load per lane and fragment, all in flight at once, landing in
         // their final registers
-        bf16x8v qf[CS_QB][KS];
-        float thrf[CS_QB];
+        bf16x8v qf[QB][KS];
+        float thrf[QB];
         if (MASKED) {                                       // this block's probe masks -> LDS
-            uint32_t* const s_mask = reinterpret_cast<uint32_t*>(csmem + CS_SLOTS * SLOT_BYTES + CS_BUF * 12);
-            for (int i = tid; i < 256 * 8; i += CS_THREADS) {
+            uint32_t* const s_mask = reinterpret_cast<uint32_t*>(csmem + NSLOT * SLOT_BYTES + CS_BUF * 12);
+            for (int i = tid; i < 256 * 8; i += THREADS) {
                 const int64_t q = qblk * 256 + (i >> 3);
                 s_mask[i] = q < a.nq ? a.probe_mask[q * 8 + (i & 7)] : 0u;
             }
             __syncthreads();
         }
         if (MODE == CS_MODE_FILTER) {                       // thresholds first: their wait must not
-            uint32_t key[CS_QB];                              // sit between the fragment loads
+            uint32_t key[QB];                              // sit between the fragment loads
 #pragma unroll
-            for (int b = 0; b < CS_QB; ++b) {
+            for (int b = 0; b < QB; ++b) {
                 const int q = qoff + 16 * b + lr;
                 key[b] = a.thr[q < a.nq ? q : a.nq - 1];
             }
 #pragma unroll
-            for (int b = 0; b < CS_QB; ++b) thrf[b] = qoff + 16 * b + lr < a.nq ? ord_unkey(key[b]) : INFINITY;
+            for (int b = 0; b < QB; ++b) thrf[b] = qoff + 16 * b + lr < a.nq ? ord_unkey(key[b]) : INFINITY;
         } else {
 #pragma unroll
-            for (int b = 0; b < CS_QB; ++b) thrf[b] = INFINITY;
+            for (int b = 0; b < QB; ++b) thrf[b] = INFINITY;
         }
 #pragma unroll
-        for (int b = 0; b < CS_QB; ++b) {
-            const uint16_t* qp = a.qhat + ((((qblk * 4 + wave) * 4 + b) * KS) * 64 + lane) * 8;
+        for (int b = 0; b < QB; ++b) {
+            const uint16_t* qp = a.qhat + (((qblk * 16 + wave * QB + b) * KS) * 64 + lane) * 8;
 #pragma unroll
             for (int s = 0; s < KS; ++s)
                 qf[b][s] = *reinterpret_cast<const bf16x8v*>(qp + (int64_t)s * 512);
@@ -475,23 +514,35 @@ __global__ __launch_bounds__(CS_THREADS) void coarse_scan_kernel(const CoarseArg
         issue(j0, 0);
         if (seg > 1) issue(j0 + 1, 1);
 #pragma unroll
-        for (int b = 0; b < CS_QB; ++b) {
+        for (int b = 0; b < QB; ++b) {
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 // pin each fragment in its register file (see mfma_bf16_q)
-                if (b * KS + s < CS_QA) asm volatile("" : "=a"(qf[b][s]) : "0"(qf[b][s]));
+                if (b * KS + s < QA) asm volatile("" : "=a"(qf[b][s]) : "0"(qf[b][s]));
                 else asm volatile("" : "=v"(qf[b][s]) : "0"(qf[b][s]));
             }
         }
         // ordinary loads are all consumed here; until the span ends only LDS-DMA is in flight
         // (plus the rare flush)
 
+        // (Measured dead end for the 8-wave kernels: waves 4-7 running one tile behind -- epilogue of
+        // tile t-1 first, then tile t's MFMAs, so that the two waves of a SIMD are in opposite phases --
+        // was 2-5 us SLOWER than letting both run in step: 65.6-68.8 vs 63.6 us at config 2.)
+        f32x4v acc[QB];
+        f32x4v rcv[4];                                       // constants of rows 4 lg .. 4 lg + 3
         int slot = 0;
-        for (int64_t t = 0; t < seg; ++t) {
+        const int64_t n_int = seg;
+        // AURA_CS_DBG bit 64: per-wave phase times (100 MHz ticks) into a.gmax (FILTER launches only)
+        const bool tm = MODE == CS_MODE_FILTER && (a.dbg & 64) && a.gmax != nullptr;
+        uint32_t tacc[6] = {0u, 0u, 0u, 0u, 0u, 0u};       // wait+barrier, check+issue, -, mma, write-out, epi
+        auto stamp = [&]() -> uint32_t { return tm ? (uint32_t)__builtin_amdgcn_s_memrealtime() : 0u; };
+        for (int64_t t = 0; t < n_int; ++t) {
+            const uint32_t ts0 = stamp();
             if (t + 1 < seg) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(GL) : "memory");
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            const uint32_t ts1 = stamp();
             const int par = (int)(t & 1);
             // The half tile t-1 appended to is stable during this tile.  Once it holds enough entries
             // it is written out in two steps that never stall the stream: the slot reservations
@@ -505,23 +556,22 @@ __global__ __launch_bounds__(CS_THREADS) void coarse_scan_kernel(const CoarseArg
                     const uint32_t eb = buf_addr + (par ^ 1) * (HALF * 12);
                     if (tid < fl_n)
                         gatomic_inc_nowait(a.cnt + (int64_t)lds_read_i32(eb + tid * 12) * CNT_STRIDE, fl_pos0);
-                    if (tid + CS_THREADS < fl_n)
-                        gatomic_inc_nowait(a.cnt + (int64_t)lds_read_i32(eb + (tid + CS_THREADS) * 12) * CNT_STRIDE,
+                    if (THREADS < HALF && tid + THREADS < fl_n)
+                        gatomic_inc_nowait(a.cnt + (int64_t)lds_read_i32(eb + (tid + THREADS) * 12) * CNT_STRIDE,
                                            fl_pos1);
                 }
             }
-            if (t + 2 < seg && !(a.dbg & 4)) issue(j0 + t + 2, slot == 0 ? 2 : slot - 1);
+            if (t + 2 < seg && !(a.dbg & 4)) issue(j0 + t + 2, (slot + 2) % NSLOT);
 
+            auto mma = [&]() {
             const char* const sb = csmem + slot * SLOT_BYTES;
-            f32x4v acc[CS_QB];
 #pragma unroll
-            for (int b = 0; b < CS_QB; ++b)
+            for (int b = 0; b < QB; ++b)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[b][e] = 0.0f;
-            f32x4v rcv[4];                                   // constants of rows 4 lg .. 4 lg + 3
             // fragment reads run two k-steps ahead of the MFMAs (one wave per SIMD: nothing else
             // hides the LDS latency)
-            constexpr int PF = SRC16 ? CS_PF16 : 2;         // k-steps the reads run ahead
+            constexpr int PF = (SRC16 && NW == 4) ? CS_PF16 : 2;   // k-steps the reads run ahead (8 waves: registers are short, the other wave hides the latency)
             f32x4v xr[PF + 1][2];
             if (!(a.dbg & 1)) {
 #pragma unroll
@@ -551,8 +601,8 @@ __global__ __launch_bounds__(CS_THREADS) void coarse_scan_kernel(const CoarseArg
                     af = __builtin_convertvector(x, bf16x8v);
                 }
 #pragma unroll
-                for (int b = 0; b < CS_QB; ++b) {
-                    if (b * KS + s < CS_QA) {
+                for (int b = 0; b < QB; ++b) {
+                    if (b * KS + s < QA) {
                         if (s == KS - 1) mfma_bf16_q<true, true>(acc[b], af, qf[b][s]);
                         else mfma_bf16_q<true, false>(acc[b], af, qf[b][s]);
                     } else {
@@ -570,56 +620,45 @@ __global__ __launch_bounds__(CS_THREADS) void coarse_scan_kernel(const CoarseArg
             }
             lds_wait4(rcv[0], rcv[1], rcv[2], rcv[3]);
             __builtin_amdgcn_sched_barrier(0);
-            if (MODE == CS_MODE_FILTER && fl_n > 0) {       // second step of the write-out (uniform)
-                if (t + 2 < seg) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GL) : "memory");   // reservations are older
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                const uint32_t eb = buf_addr + (par ^ 1) * (HALF * 12);
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int i = tid + u * CS_THREADS;
-                    const int pos = u == 0 ? fl_pos0 : fl_pos1;
-                    if (i < fl_n && pos < a.cap) {
-                        uint32_t eq, er, eu;
-                        lds_read3(eb + i * 12, eq, er, eu);
-                        a.cand_scores[(int64_t)eq * a.cap + pos] = __uint_as_float(eu);
-                        a.cand_idx[(int64_t)eq * a.cap + pos] = (int32_t)er;
-                    }
-                }
-                if (tid == 0) lds_write_i32(nb_addr + (par ^ 1) * 4, 0);   // seen by all after the next barrier
-            }
-
+            };
+            auto epi = [&](int64_t tt) {
             // ---- epilogue: rows 4 lg + e of the tile, queries qoff + 16 b + lr ----
-            const int64_t r0 = tile_row0(j0 + t);
+            const int64_t r0 = tile_row0(j0 + tt);
             const int rows_left = (int)((a.N - r0) < CS_ROWS ? (a.N - r0) : CS_ROWS);
-            float gm[CS_QB];
+            float gm[QB];
             unsigned bits = 0u;
             if (!(a.dbg & 2)) {
 #pragma unroll
-            for (int b = 0; b < CS_QB; ++b) gm[b] = -INFINITY;
+            for (int b = 0; b < QB; ++b) gm[b] = -INFINITY;
             unsigned allow = 0xffffu;                        // bit 4 b + e: pair passes the probe mask
             if (MASKED) {
                 // 16 mask words (4 rows x 4 query blocks) by inline-asm LDS reads, one wait
-                uint32_t mw[16];
+                uint32_t mw[4 * QB];
                 int cidv[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int cid = (int)rcv[e][3];
                     cidv[e] = (cid >= 0 && cid < 256) ? cid : -1;
 #pragma unroll
-                    for (int b = 0; b < CS_QB; ++b)
+                    for (int b = 0; b < QB; ++b)
                         asm volatile("ds_read_b32 %0, %1" : "=v"(mw[b * 4 + e])
-                                     : "v"(mask_addr + (uint32_t)((wave * 64 + 16 * b + lr) * 32 + ((cidv[e] < 0 ? 0 : cidv[e]) >> 5) * 4))
+                                     : "v"(mask_addr + (uint32_t)((wave * (16 * QB) + 16 * b + lr) * 32 + ((cidv[e] < 0 ? 0 : cidv[e]) >> 5) * 4))
                                      : "memory");
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)"
-                             : "+v"(mw[0]), "+v"(mw[1]), "+v"(mw[2]), "+v"(mw[3]), "+v"(mw[4]), "+v"(mw[5]),
-                               "+v"(mw[6]), "+v"(mw[7]), "+v"(mw[8]), "+v"(mw[9]), "+v"(mw[10]), "+v"(mw[11]),
-                               "+v"(mw[12]), "+v"(mw[13]), "+v"(mw[14]), "+v"(mw[15])::"memory");
+                if constexpr (QB == 4)
+                    asm volatile("s_waitcnt lgkmcnt(0)"
+                                 : "+v"(mw[0]), "+v"(mw[1]), "+v"(mw[2]), "+v"(mw[3]), "+v"(mw[4]), "+v"(mw[5]),
+                                   "+v"(mw[6]), "+v"(mw[7]), "+v"(mw[8]), "+v"(mw[9]), "+v"(mw[10]), "+v"(mw[11]),
+                                   "+v"(mw[12]), "+v"(mw[13]), "+v"(mw[14]), "+v"(mw[15])::"memory");
+                else
+                    asm volatile("s_waitcnt lgkmcnt(0)"
+                                 : "+v"(mw[0]), "+v"(mw[1]), "+v"(mw[2]), "+v"(mw[3]), "+v"(mw[4]), "+v"(mw[5]),
+                                   "+v"(mw[6]), "+v"(mw[7])::"memory");
                 allow = 0u;
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
-                    for (int b = 0; b < CS_QB; ++b)
+                    for (int b = 0; b < QB; ++b)
                         allow |= (cidv[e] >= 0 && ((mw[b * 4 + e] >> (cidv[e] & 31)) & 1u)) ? (1u << (b * 4 + e)) : 0u;
             }
 #pragma unroll
@@ -627,7 +666,7 @@ __global__ __launch_bounds__(CS_THREADS) void coarse_scan_kernel(const CoarseArg
                 const f32x4v rc = rcv[e];
                 const bool vrow = 4 * lg + e < rows_left;
 #pragma unroll
-                for (int b = 0; b < CS_QB; ++b) {
+                for (int b = 0; b < QB; ++b) {
                     const bool ok = vrow && ((allow >> (b * 4 + e)) & 1u);
                     if (MODE == CS_MODE_SAMPLE) {
                         gm[b] = fmaxf(gm[b], ok ? acc[b][e] * rc[0] + rc[2] : -INFINITY);
@@ -641,7 +680,7 @@ __global__ __launch_bounds__(CS_THREADS) void coarse_scan_kernel(const CoarseArg
             }
             if (MODE == CS_MODE_SAMPLE) {
 #pragma unroll
-                for (int b = 0; b < CS_QB; ++b) {
+                for (int b = 0; b < QB; ++b) {
                     float mx = gm[b];
                     mx = fmaxf(mx, __shfl_xor(mx, 16));
                     const int q = qoff + 16 * b + lr;
@@ -649,10 +688,10 @@ __global__ __launch_bounds__(CS_THREADS) void coarse_scan_kernel(const CoarseArg
                         // inverted lists: 8-row groups (rows 0-7 = lg 0,1; rows 8-15 = lg 2,3), two per
                         // tile, so that a query probing a single list still has 64 groups for its bound
                         if ((lg & 1) == 0 && q < a.nq)
-                            a.gmax[(int64_t)q * a.gmax_ld + 2 * (j0 + t) + (lg >> 1)] = mx;
+                            a.gmax[(int64_t)q * a.gmax_ld + 2 * (j0 + tt) + (lg >> 1)] = mx;
                     } else {
                         mx = fmaxf(mx, __shfl_xor(mx, 32));
-                        if (lg == 0 && q < a.nq) a.gmax[(int64_t)q * a.gmax_ld + (j0 + t)] = mx;
+                        if (lg == 0 && q < a.nq) a.gmax[(int64_t)q * a.gmax_ld + (j0 + tt)] = mx;
                     }
                 }
             } else if (!(a.dbg & 32)) {
@@ -673,7 +712,7 @@ __global__ __launch_bounds__(CS_THREADS) void coarse_scan_kernel(const CoarseArg
                         const int idx = __ffs(rem) - 1;      // = 4 b + e
                         float u = acc[0][0];
 #pragma unroll
-                        for (int i = 1; i < 16; ++i) u = idx == i ? acc[i >> 2][i & 3] : u;
+                        for (int i = 1; i < 4 * QB; ++i) u = idx == i ? acc[i >> 2][i & 3] : u;
                         const int p = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
                                           __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
                         int q = qoff + 16 * (idx >> 2) + lr;
@@ -702,7 +741,43 @@ __global__ __launch_bounds__(CS_THREADS) void coarse_scan_kernel(const CoarseArg
                     }
                 }
             }
-            slot = slot == 2 ? 0 : slot + 1;
+            };
+            const uint32_t ts2 = stamp();
+            const uint32_t ts3 = ts2;
+            mma();
+            const uint32_t ts4 = stamp();
+            if (MODE == CS_MODE_FILTER && fl_n > 0) {       // second step of the write-out (uniform)
+                if (t + 2 < seg) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GL) : "memory");   // reservations are older
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const uint32_t eb = buf_addr + (par ^ 1) * (HALF * 12);
+#pragma unroll
+                for (int u = 0; u < HALF / THREADS; ++u) {
+                    const int i = tid + u * THREADS;
+                    const int pos = u == 0 ? fl_pos0 : fl_pos1;
+                    if (i < fl_n && pos < a.cap) {
+                        uint32_t eq, er, eu;
+                        lds_read3(eb + i * 12, eq, er, eu);
+                        a.cand_scores[(int64_t)eq * a.cap + pos] = __uint_as_float(eu);
+                        a.cand_idx[(int64_t)eq * a.cap + pos] = (int32_t)er;
+                    }
+                }
+                if (tid == 0) lds_write_i32(nb_addr + (par ^ 1) * 4, 0);   // seen by all after the next barrier
+            }
+
+            const uint32_t ts5 = stamp();
+            epi(t);
+            if (tm) {
+                const uint32_t ts6 = stamp();
+                tacc[0] += ts1 - ts0; tacc[1] += ts2 - ts1; tacc[2] += ts3 - ts2;
+                tacc[3] += ts4 - ts3; tacc[4] += ts5 - ts4; tacc[5] += ts6 - ts5;
+            }
+            slot = (slot + 1) % NSLOT;
+        }
+        if (tm && lane == 0) {
+            float* const o = a.gmax + ((int64_t)blockIdx.x * 8 + wave) * 8;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) o[i] += (float)tacc[i];
+            o[6] += (float)seg;
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -924,35 +999,47 @@ inline bool coarse_eligible(const float* bank, const uint16_t* bank16, const flo
     return true;
 }
 
-template <int KS, bool SRC16, bool MASKED>
+template <int KS, bool SRC16, bool MASKED, int NW = 4>
 inline int launch_coarse(const CoarseArgs& a, int mode, int grid, hipStream_t s) {
     const size_t lds = (size_t)CS_SLOTS * (KS * (SRC16 ? 1024 : 2048) + CS_AUX_BYTES) + (size_t)CS_BUF * 12 +
                        (MASKED ? 256 * 32 : 0);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(coarse_scan_kernel<KS, CS_MODE_SAMPLE, SRC16, MASKED>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(coarse_scan_kernel<KS, CS_MODE_SAMPLE, SRC16, MASKED, false, NW>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(coarse_scan_kernel<KS, CS_MODE_FILTER, SRC16, MASKED>),
+            hipFuncSetAttribute(reinterpret_cast<const void*>(coarse_scan_kernel<KS, CS_MODE_FILTER, SRC16, MASKED, false, NW>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return AURA_E_LAUNCH;
         attr_set = true;
     }
     if (mode == CS_MODE_SAMPLE)
-        hipLaunchKernelGGL((coarse_scan_kernel<KS, CS_MODE_SAMPLE, SRC16, MASKED>), dim3(grid), dim3(CS_THREADS), lds, s, a);
+        hipLaunchKernelGGL((coarse_scan_kernel<KS, CS_MODE_SAMPLE, SRC16, MASKED, false, NW>), dim3(grid), dim3(64 * NW), lds, s, a);
     else
-        hipLaunchKernelGGL((coarse_scan_kernel<KS, CS_MODE_FILTER, SRC16, MASKED>), dim3(grid), dim3(CS_THREADS), lds, s, a);
+        hipLaunchKernelGGL((coarse_scan_kernel<KS, CS_MODE_FILTER, SRC16, MASKED, false, NW>), dim3(grid), dim3(64 * NW), lds, s, a);
     return check_launch();
 }
 
 inline int dispatch_coarse(const CoarseArgs& a, int mode, int grid, hipStream_t s) {
     const int64_t ks = (a.D + 31) / 32;
+    // bf16-row kernels run 8 waves per workgroup (two per SIMD) unless AURA_CS_WAVES4 is set (A/B runs)
+    static const bool w4 = getenv("AURA_CS_WAVES4") != nullptr;
     if (a.bank16 && a.probe_mask) {
+        if (!w4) {
+            if (ks <= 8) return launch_coarse<8, true, true, 8>(a, mode, grid, s);
+            if (ks <= 16) return launch_coarse<16, true, true, 8>(a, mode, grid, s);
+            return launch_coarse<24, true, true, 8>(a, mode, grid, s);
+        }
         if (ks <= 8) return launch_coarse<8, true, true>(a, mode, grid, s);
         if (ks <= 16) return launch_coarse<16, true, true>(a, mode, grid, s);
         return launch_coarse<24, true, true>(a, mode, grid, s);
     }
     if (a.probe_mask) return AURA_E_INVAL;                   // masked mode needs the bf16 rows
     if (a.bank16) {
+        if (!w4) {
+            if (ks <= 8) return launch_coarse<8, true, false, 8>(a, mode, grid, s);
+            if (ks <= 16) return launch_coarse<16, true, false, 8>(a, mode, grid, s);
+            return launch_coarse<24, true, false, 8>(a, mode, grid, s);
+        }
         if (ks <= 8) return launch_coarse<8, true, false>(a, mode, grid, s);
         if (ks <= 16) return launch_coarse<16, true, false>(a, mode, grid, s);
         return launch_coarse<24, true, false>(a, mode, grid, s);

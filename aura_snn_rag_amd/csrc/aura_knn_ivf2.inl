@@ -258,21 +258,21 @@ static Ivf2Workspace carve_ivf2(void* base, int64_t Npad, int64_t nq, int k) {
     return w;
 }
 
-template <int KS>
+template <int KS, int NW>
 inline int launch_coarse_ivf(const CoarseArgs& a, int mode, int grid, hipStream_t s) {
     const size_t lds = (size_t)CS_SLOTS * (KS * 1024 + CS_AUX_BYTES) + (size_t)CS_BUF * 12 + 256 * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(coarse_scan_kernel<KS, CS_MODE_SAMPLE, true, false, true>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(coarse_scan_kernel<KS, CS_MODE_SAMPLE, true, false, true, NW>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(coarse_scan_kernel<KS, CS_MODE_FILTER, true, false, true>),
+            hipFuncSetAttribute(reinterpret_cast<const void*>(coarse_scan_kernel<KS, CS_MODE_FILTER, true, false, true, NW>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return AURA_E_LAUNCH;
         attr_set = true;
     }
     if (mode == CS_MODE_SAMPLE)
-        hipLaunchKernelGGL((coarse_scan_kernel<KS, CS_MODE_SAMPLE, true, false, true>), dim3(grid), dim3(CS_THREADS), lds, s, a);
+        hipLaunchKernelGGL((coarse_scan_kernel<KS, CS_MODE_SAMPLE, true, false, true, NW>), dim3(grid), dim3(64 * NW), lds, s, a);
     else
-        hipLaunchKernelGGL((coarse_scan_kernel<KS, CS_MODE_FILTER, true, false, true>), dim3(grid), dim3(CS_THREADS), lds, s, a);
+        hipLaunchKernelGGL((coarse_scan_kernel<KS, CS_MODE_FILTER, true, false, true, NW>), dim3(grid), dim3(64 * NW), lds, s, a);
     return check_launch();
 }

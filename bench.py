@@ -419,8 +419,8 @@ def main():
                                "register-resident query fragments)",
                         achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS,
                         algorithmic_bytes_per_launch=nbytes,
-                        pmc_key=("coarse_scan_kernel<24, 1, true, false, false>" if kind == 2
-                                 else "coarse_scan_kernel<24, 1, false, false, false>"),
+                        pmc_key=("coarse_scan_kernel<24, 1, true, false, false, 8>" if kind == 2
+                                 else "coarse_scan_kernel<24, 1, false, false, false, 4>"),
                         bf16_tflops_at_kernel=tf, bf16_frac_of_2500=tf / 2500.0)
         return dict(common, bound="mfma",
                     kernel="knn_scan_filter_v2 (v_mfma_f32_32x32x2_f32, fp32 in / fp32 acc)",
