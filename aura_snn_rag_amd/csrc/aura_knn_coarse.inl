@@ -129,6 +129,34 @@ __device__ __forceinline__ void lds_read4x16_nowait(uint32_t addr, f32x4v& r0, f
                  "ds_read_b128 %2, %4 offset:32\n\tds_read_b128 %3, %4 offset:48"
                  : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3) : "v"(addr) : "memory");
 }
+// fragment reads of the MFMA loop: issued without a wait, consumed behind a COUNTED wait (LDS
+// operations return in order; n = LDS operations issued after the one being consumed).  hipcc's own
+// placement was "s_waitcnt lgkmcnt(0)" right behind a freshly issued read every PF+1 k-steps: the
+// full LDS latency, exposed, five times per tile.
+template <int OFF>
+__device__ __forceinline__ void lds_read16_nowait(f32x4v& r, uint32_t addr) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
+}
+// (the consumed registers are tied to the wait so that no use -- and no copy -- can move above it;
+// never pass the same object twice: the second operand would be a copy taken BEFORE the wait)
+template <int N>
+__device__ __forceinline__ void lds_wait_n(f32x4v& r0, f32x4v& r1) {
+    static_assert(N >= 0 && N <= 15, "lgkmcnt field");
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(r0), "+v"(r1) : "n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void lds_wait_n(f32x4v& r0) {
+    static_assert(N >= 0 && N <= 15, "lgkmcnt field");
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(r0) : "n"(N) : "memory");
+}
+template <int I, int N, class F>
+__device__ __forceinline__ void cs_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        cs_static_for<I + 1, N>(static_cast<F&&>(f));
+    }
+}
 __device__ __forceinline__ void lds_wait4(f32x4v& r0, f32x4v& r1, f32x4v& r2, f32x4v& r3) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3)::"memory");
 }
@@ -564,7 +592,6 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
             if (t + 2 < seg && !(a.dbg & 4)) issue(j0 + t + 2, (slot + 2) % NSLOT);
 
             auto mma = [&]() {
-            const char* const sb = csmem + slot * SLOT_BYTES;
 #pragma unroll
             for (int b = 0; b < QB; ++b)
 #pragma unroll
@@ -573,25 +600,30 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
             // hides the LDS latency)
             constexpr int PF = (SRC16 && NW == 4) ? CS_PF16 : 2;   // k-steps the reads run ahead (8 waves: registers are short, the other wave hides the latency)
             f32x4v xr[PF + 1][2];
+            constexpr int RP = SRC16 ? 1 : 2;                // LDS reads per k-step
+            constexpr int S_RC = KS >= 3 ? KS - 3 : 0;       // the row constants are fetched behind this step
+            const uint32_t a0 = cs_base + slot * SLOT_BYTES + off0, a1 = cs_base + slot * SLOT_BYTES + off1;
             if (!(a.dbg & 1)) {
-#pragma unroll
-            for (int s = 0; s < PF && s < KS; ++s) {
-                xr[s][0] = *reinterpret_cast<const f32x4v*>(sb + s * STEP_BYTES + off0);
-                if (!SRC16) xr[s][1] = *reinterpret_cast<const f32x4v*>(sb + s * STEP_BYTES + off1);
-            }
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-#ifdef AURA_CS_EXP_NOREAD
-                if (false) {
-#else
-                if (s + PF < KS) {
-#endif
-                    xr[(s + PF) % (PF + 1)][0] = *reinterpret_cast<const f32x4v*>(sb + (s + PF) * STEP_BYTES + off0);
-                    if (!SRC16)
-                        xr[(s + PF) % (PF + 1)][1] = *reinterpret_cast<const f32x4v*>(sb + (s + PF) * STEP_BYTES + off1);
+            cs_static_for<0, (PF < KS ? PF : KS)>([&](auto S) {
+                constexpr int s = decltype(S)::value;
+                lds_read16_nowait<s * STEP_BYTES>(xr[s][0], a0);
+                if constexpr (!SRC16) lds_read16_nowait<s * STEP_BYTES>(xr[s][1], a1);
+            });
+            cs_static_for<0, KS>([&](auto S) {
+                constexpr int s = decltype(S)::value;
+#ifndef AURA_CS_EXP_NOREAD
+                if constexpr (s + PF < KS) {
+                    lds_read16_nowait<(s + PF) * STEP_BYTES>(xr[(s + PF) % (PF + 1)][0], a0);
+                    if constexpr (!SRC16) lds_read16_nowait<(s + PF) * STEP_BYTES>(xr[(s + PF) % (PF + 1)][1], a1);
                 }
+#endif
+                // younger than this step's reads: the reads of the next min(PF, KS-1-s) steps and, behind
+                // step S_RC, the four row-constant reads
+                constexpr int YOUNGER = RP * ((KS - 1 - s) < PF ? (KS - 1 - s) : PF) + (s > S_RC ? 4 : 0);
+                if constexpr (SRC16) lds_wait_n<YOUNGER>(xr[s % (PF + 1)][0]);
+                else lds_wait_n<YOUNGER>(xr[s % (PF + 1)][0], xr[s % (PF + 1)][1]);
                 bf16x8v af;
-                if (SRC16) {
+                if constexpr (SRC16) {
                     af = __builtin_bit_cast(bf16x8v, xr[s % (PF + 1)][0]);
                 } else {
                     const f32x4v x0 = xr[s % (PF + 1)][0], x1 = xr[s % (PF + 1)][1];
@@ -611,10 +643,10 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
                     }
                 }
                 // the epilogue's row constants are fetched behind the last two k-steps
-                if (s == (KS >= 3 ? KS - 3 : 0))
+                if constexpr (s == S_RC)
                     lds_read4x16_nowait(cs_base + slot * SLOT_BYTES + TILE_BYTES + lg * 64, rcv[0], rcv[1], rcv[2], rcv[3]);
                 __builtin_amdgcn_sched_barrier(0);
-            }
+            });
             } else {
                 lds_read4x16_nowait(cs_base + slot * SLOT_BYTES + TILE_BYTES + lg * 64, rcv[0], rcv[1], rcv[2], rcv[3]);
             }
@@ -1024,11 +1056,8 @@ inline int dispatch_coarse(const CoarseArgs& a, int mode, int grid, hipStream_t 
     // bf16-row kernels run 8 waves per workgroup (two per SIMD) unless AURA_CS_WAVES4 is set (A/B runs)
     static const bool w4 = getenv("AURA_CS_WAVES4") != nullptr;
     if (a.bank16 && a.probe_mask) {
-        if (!w4) {
-            if (ks <= 8) return launch_coarse<8, true, true, 8>(a, mode, grid, s);
-            if (ks <= 16) return launch_coarse<16, true, true, 8>(a, mode, grid, s);
-            return launch_coarse<24, true, true, 8>(a, mode, grid, s);
-        }
+        // (the masked epilogue's mask words do not fit the 256-register budget at D = 768: its 8-wave
+        // form spills fragments inside the tile loop, so this mode keeps one wave per SIMD)
         if (ks <= 8) return launch_coarse<8, true, true>(a, mode, grid, s);
         if (ks <= 16) return launch_coarse<16, true, true>(a, mode, grid, s);
         return launch_coarse<24, true, true>(a, mode, grid, s);
