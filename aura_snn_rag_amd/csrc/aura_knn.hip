@@ -1764,7 +1764,24 @@ inline int run_coarse_pass(const float* bank, const uint16_t* bank16, const floa
     r.now = now; r.e_cos = e_cos; r.N = N; r.D = D; r.k = k; r.cnt = w.cnt;
     r.cand_scores = w.cand_scores; r.cand_idx = w.cand_idx; r.cap = w.cap; r.idx_base = idx_base;
     r.out_scores = out_scores; r.out_idx = out_idx; r.overflow = overflow_out;
+    static int rtm_left = 3;                                 // AURA_CS_DBG bit 128: refine phase times
+    const bool rtm = (cs_dbg & 128) && rtm_left > 0;
+    if (rtm) r.dbg_out = w.gmax;
     if ((rc = launch_refine_for(r, nqb, D, cus, s))) return rc;
+    if (rtm) {
+        --rtm_left;
+        (void)hipStreamSynchronize(s);
+        std::vector<float> h((size_t)nqb * 8);
+        (void)hipMemcpy(h.data(), w.gmax, h.size() * 4, hipMemcpyDeviceToHost);
+        static const char* const names[6] = {"load candidates", "select T2", "survivors", "load query", "re-score", "rank+write"};
+        double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, mx[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int q = 0; q < nqb; ++q)
+            for (int i = 0; i < 8; ++i) { sum[i] += h[(size_t)q * 8 + i]; if (h[(size_t)q * 8 + i] > mx[i]) mx[i] = h[(size_t)q * 8 + i]; }
+        fprintf(stderr, "[refine phases] %d queries: candidates mean %.0f max %.0f, survivors mean %.0f max %.0f;", nqb,
+                sum[6] / nqb, mx[6], sum[7] / nqb, mx[7]);
+        for (int i = 0; i < 6; ++i) fprintf(stderr, " %s %.2f us (max %.2f);", names[i], sum[i] / nqb * 0.01, mx[i] * 0.01);
+        fprintf(stderr, "\n");
+    }
     return check_launch();
 }
 

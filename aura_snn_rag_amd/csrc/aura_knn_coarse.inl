@@ -435,7 +435,7 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
                 glds16(reinterpret_cast<const float*>(base + (ld_rho * D + kf) * ESZ), sb + i * (1024 * NW));
             }
         }
-        {   // row constants (every wave issues the same piece: uniform vmcnt, same bytes)
+        if (wave == 0) {   // row constants: one piece per tile, from wave 0 (its vmcnt waits count one more)
             int64_t row = r0 + (lane & 15);
             if (row >= a.N) row = a.N - 1;
             glds16(reinterpret_cast<const float*>(a.rowc + row), csmem + slot * SLOT_BYTES + TILE_BYTES);
@@ -566,8 +566,11 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
         auto stamp = [&]() -> uint32_t { return tm ? (uint32_t)__builtin_amdgcn_s_memrealtime() : 0u; };
         for (int64_t t = 0; t < n_int; ++t) {
             const uint32_t ts0 = stamp();
-            if (t + 1 < seg) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(GL) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            // this tile's pieces have landed; the next tile's (NP per wave, + the row constants on wave 0)
+            // stay in flight
+            if (t + 1 >= seg) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            else if (wave == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(GL) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NP) : "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             const uint32_t ts1 = stamp();
@@ -658,6 +661,7 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
             const int64_t r0 = tile_row0(j0 + tt);
             const int rows_left = (int)((a.N - r0) < CS_ROWS ? (a.N - r0) : CS_ROWS);
             float gm[QB];
+            float uv[4 * QB];                                // U of the tile's pairs (kept out of the AGPR accumulators)
             unsigned bits = 0u;
             if (!(a.dbg & 2)) {
 #pragma unroll
@@ -704,7 +708,7 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
                         gm[b] = fmaxf(gm[b], ok ? acc[b][e] * rc[0] + rc[2] : -INFINITY);
                     } else {
                         const float up = acc[b][e] * rc[0] + rc[1];
-                        acc[b][e] = up;
+                        uv[b * 4 + e] = up;
                         bits |= (ok && up >= thrf[b]) ? (1u << (b * 4 + e)) : 0u;   // thrf = +inf: q >= nq
                     }
                 }
@@ -742,9 +746,9 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
                     base = __builtin_amdgcn_readlane(base, first);
                     if (rem != 0u) {
                         const int idx = __ffs(rem) - 1;      // = 4 b + e
-                        float u = acc[0][0];
+                        float u = uv[0];
 #pragma unroll
-                        for (int i = 1; i < 4 * QB; ++i) u = idx == i ? acc[i >> 2][i & 3] : u;
+                        for (int i = 1; i < 4 * QB; ++i) u = idx == i ? uv[i] : u;
                         const int p = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
                                           __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
                         int q = qoff + 16 * (idx >> 2) + lr;
@@ -779,8 +783,9 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
             mma();
             const uint32_t ts4 = stamp();
             if (MODE == CS_MODE_FILTER && fl_n > 0) {       // second step of the write-out (uniform)
-                if (t + 2 < seg) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GL) : "memory");   // reservations are older
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (t + 2 >= seg) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (wave == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GL) : "memory");   // reservations are older
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
                 const uint32_t eb = buf_addr + (par ^ 1) * (HALF * 12);
 #pragma unroll
                 for (int u = 0; u < HALF / THREADS; ++u) {
@@ -843,6 +848,7 @@ struct RefineArgs {
     float* out_scores;          // [nq][k]
     int32_t* out_idx;
     int32_t* overflow;
+    float* dbg_out;             // AURA_CS_DBG bit 128: [nq][8] phase times (100 MHz ticks), n, S
 };
 
 template <int RF_ROWS, int RF_KC>
@@ -862,6 +868,10 @@ __global__ __launch_bounds__(RF_THREADS) void coarse_refine_kernel(const RefineA
     const int q = blockIdx.x, tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int64_t D = a.D;
+    const bool tm = a.dbg_out != nullptr;
+    uint32_t tst[7] = {0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    auto stamp = [&](int i) { if (tm) tst[i] = (uint32_t)__builtin_amdgcn_s_memrealtime(); };
+    stamp(0);
     int n = a.cnt[(int64_t)q * CNT_STRIDE];
     bool ovf = false;
     const int capn = a.cap < RF_CAP ? a.cap : RF_CAP;
@@ -882,6 +892,7 @@ __global__ __launch_bounds__(RF_THREADS) void coarse_refine_kernel(const RefineA
     }
     if (tid == 0) { s_ns = 0; s_prefix = 0u; s_sel_k = a.k; }
     __syncthreads();
+    stamp(1);
 
     // ---- T2 = k-th largest L: MSB-first 8-bit radix select, the digit found by a parallel suffix
     //      scan of the 256-bin histogram; everything survives if n < k ----
@@ -921,6 +932,7 @@ __global__ __launch_bounds__(RF_THREADS) void coarse_refine_kernel(const RefineA
         }
         t2 = s_prefix;
     }
+    stamp(2);
     // ---- survivors: U >= T2 ----
     for (int i = tid; i < n; i += RF_THREADS) {
         if (ord_key(s_u[i]) >= t2) {
@@ -941,8 +953,10 @@ __global__ __launch_bounds__(RF_THREADS) void coarse_refine_kernel(const RefineA
     float* const s_rows = reinterpret_cast<float*>(rsmem) + wave * (RF_ROWS * RSTRIDE);
     float* const s_q = reinterpret_cast<float*>(rsmem) + 8 * (RF_ROWS * RSTRIDE);   // [Dpad]
     const int64_t Dpad = (D + 31) / 32 * 32;
+    stamp(3);
     for (int64_t i = tid; i < Dpad; i += RF_THREADS) s_q[i] = i < D ? a.queries[(int64_t)q * D + i] : 0.0f;
     __syncthreads();
+    stamp(4);
     const float iq = a.inv_q[q];
     const bool ld_lane = lane * 4 < RF_KC;                   // lanes that move a row chunk
     for (int base = 0; base < S; base += 8 * RF_ROWS) {
@@ -976,6 +990,9 @@ __global__ __launch_bounds__(RF_THREADS) void coarse_refine_kernel(const RefineA
             if (lane < RF_ROWS) {
                 const float* rp = s_rows + lane * RSTRIDE;
                 const float* qp = s_q + k0;
+                // (measured: running the LDS reads four groups ahead of the chain changes nothing -- the
+                // phase is bound by the gather of the survivors' fp32 rows, 256 x 71 x 3 KB = 56 MB of
+                // random 1-KB pieces per launch at ~4 TB/s; AURA_CS_DBG=128 prints the phase times)
 #pragma unroll 4
                 for (int kk = 0; kk < kc; kk += 8) {
                     const float4 b0 = *reinterpret_cast<const float4*>(rp + kk);
@@ -1003,6 +1020,7 @@ __global__ __launch_bounds__(RF_THREADS) void coarse_refine_kernel(const RefineA
         }
     }
     __syncthreads();
+    stamp(5);
     // ---- rank the survivors' exact keys (all distinct) and write the top k, sorted ----
     for (int i = tid; i < S; i += RF_THREADS) {
         const unsigned long long mine = s_key[i];
@@ -1016,6 +1034,15 @@ __global__ __launch_bounds__(RF_THREADS) void coarse_refine_kernel(const RefineA
     for (int i = S + tid; i < a.k; i += RF_THREADS) {       // fewer than k rows can score (never when k <= N)
         a.out_scores[(int64_t)q * a.k + i] = -INFINITY;
         a.out_idx[(int64_t)q * a.k + i] = -1;
+    }
+    if (tm) {
+        __syncthreads();
+        stamp(6);
+        if (tid == 0) {
+            float* const o = a.dbg_out + (int64_t)q * 8;
+            for (int i = 0; i < 6; ++i) o[i] = (float)(tst[i + 1] - tst[i]);
+            o[6] = (float)n; o[7] = (float)S;
+        }
     }
 }
 
