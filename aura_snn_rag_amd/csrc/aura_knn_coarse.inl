@@ -360,8 +360,7 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
     constexpr int GL = NP + 1;                             // global_load_lds per wave and tile
     constexpr int NSLOT = CS_SLOTS;                        // ring slots
     extern __shared__ __attribute__((aligned(16))) char csmem[];
-    // candidate buffer [2][CS_BUF/2][3] follows the slots (addressed through buf_addr)
-    __shared__ int s_nb[2];
+    // candidate buffer [NW][2][WCAP][3] follows the slots (addressed through buf_addr)
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -373,8 +372,6 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
     const int64_t total = IVF ? (int64_t)a.item_off[ivf_nblk] : a.n_tiles * nqblk;
     const int64_t lo = total * (int64_t)blockIdx.x / gridDim.x;
     const int64_t hi = total * ((int64_t)blockIdx.x + 1) / gridDim.x;
-    if (tid < 2) s_nb[tid] = 0;
-    __syncthreads();
 
     // Reader offsets inside a k-step block (lane = row lr, k-group lg), XOR-swizzled so that the 16
     // lanes of a ds_read_b128 phase hit 16 different bank quads:
@@ -442,39 +439,44 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
         }
     };
 
-    // candidate buffer: two halves; tile t appends to half t&1, so the other half is stable during
-    // tile t and can be inspected / flushed without any extra barrier
-    constexpr int HALF = CS_BUF / 2;
-    const uint32_t nb_addr = lds_addr(s_nb), cs_base = lds_addr(csmem);
+    // Candidate buffer: every wave owns a region of two halves of WCAP entries (q, row, U) and keeps
+    // the halves' fill counts in scalar registers -- no LDS atomics, no shared counters, no cross-wave
+    // ordering.  Tile t appends to half t&1; the other half is stable during tile t and is written out
+    // (by its own wave) once it holds WFLUSH entries; entries beyond WCAP go straight to the lists.
+    constexpr int WCAP = CS_BUF / (2 * NW);                // 64 (8 waves) or 128 (4 waves)
+    constexpr int EPL = WCAP / 64;                         // entries per lane and half in a write-out
+    constexpr int WFLUSH = WCAP / 4;
+    const uint32_t cs_base = lds_addr(csmem);
     const uint32_t buf_addr = cs_base + NSLOT * SLOT_BYTES;
+    const uint32_t wreg_addr = buf_addr + wave * (2 * WCAP * 12);
     const uint32_t mask_addr = buf_addr + CS_BUF * 12;            // [256][8] probe masks (MASKED) / [256] slot -> query (IVF)
+    int wc[2] = {0, 0};                                    // fill counts of this wave's halves (wave-uniform)
     // span-end write-out of both halves: every slot reservation is issued before any is waited for
-    // (up to 4 entries per thread), then one wait, then the stores
-    auto flush_all = [&](int n0, int n1) {
-        n0 = n0 < HALF ? n0 : HALF;
-        n1 = n1 < HALF ? n1 : HALF;
-        constexpr int EPT = HALF / THREADS;               // entries per thread and half
+    // (up to 4 entries per lane), then one wait, then the stores
+    auto flush_all = [&]() {
         int pos[4] = {-1, -1, -1, -1};
         uint32_t eq[4], er[4], eu[4];
 #pragma unroll
-        for (int u = 0; u < 2 * EPT; ++u) {
-            const int i = tid + (u % EPT) * THREADS, h = u / EPT;
+        for (int u = 0; u < 2 * EPL; ++u) {
+            const int i = lane + (u % EPL) * 64, h = u / EPL;
+            const int nh = wc[h] < WCAP ? wc[h] : WCAP;
             pos[u] = -1;
-            if (i < (h ? n1 : n0)) {
-                lds_read3(buf_addr + (h * HALF + i) * 12, eq[u], er[u], eu[u]);
+            if (i < nh) {
+                lds_read3(wreg_addr + (h * WCAP + i) * 12, eq[u], er[u], eu[u]);
                 gatomic_inc_nowait(a.cnt + (int64_t)eq[u] * CNT_STRIDE, pos[u]);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(pos[0]), "+v"(pos[1]), "+v"(pos[2]), "+v"(pos[3])::"memory");
 #pragma unroll
-        for (int u = 0; u < 2 * EPT; ++u) {
-            const int i = tid + (u % EPT) * THREADS, h = u / EPT;
-            if (i < (h ? n1 : n0) && pos[u] < a.cap) {
+        for (int u = 0; u < 2 * EPL; ++u) {
+            const int i = lane + (u % EPL) * 64, h = u / EPL;
+            const int nh = wc[h] < WCAP ? wc[h] : WCAP;
+            if (i < nh && pos[u] < a.cap) {
                 a.cand_scores[(int64_t)eq[u] * a.cap + pos[u]] = __uint_as_float(eu[u]);
                 a.cand_idx[(int64_t)eq[u] * a.cap + pos[u]] = (int32_t)er[u];
             }
         }
-        if (tid < 2) lds_write_i32(nb_addr + tid * 4, 0);
+        wc[0] = 0; wc[1] = 0;
     };
 
     int64_t c = lo;
@@ -581,14 +583,14 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
             // the MFMA loop with a counted wait.
             int fl_n = 0, fl_pos0 = 0, fl_pos1 = 0;
             if (MODE == CS_MODE_FILTER) {
-                const int nbo = __builtin_amdgcn_readfirstlane(lds_read_i32(nb_addr + (par ^ 1) * 4));
-                if (nbo >= CS_FLUSH_MIN) {
-                    fl_n = nbo < HALF ? nbo : HALF;
-                    const uint32_t eb = buf_addr + (par ^ 1) * (HALF * 12);
-                    if (tid < fl_n)
-                        gatomic_inc_nowait(a.cnt + (int64_t)lds_read_i32(eb + tid * 12) * CNT_STRIDE, fl_pos0);
-                    if (THREADS < HALF && tid + THREADS < fl_n)
-                        gatomic_inc_nowait(a.cnt + (int64_t)lds_read_i32(eb + (tid + THREADS) * 12) * CNT_STRIDE,
+                const int nbo = wc[par ^ 1];                 // (wave-uniform, in scalar registers)
+                if (nbo >= WFLUSH) {
+                    fl_n = nbo < WCAP ? nbo : WCAP;
+                    const uint32_t eb = wreg_addr + (par ^ 1) * (WCAP * 12);
+                    if (lane < fl_n)
+                        gatomic_inc_nowait(a.cnt + (int64_t)lds_read_i32(eb + lane * 12) * CNT_STRIDE, fl_pos0);
+                    if (EPL > 1 && lane + 64 < fl_n)
+                        gatomic_inc_nowait(a.cnt + (int64_t)lds_read_i32(eb + (lane + 64) * 12) * CNT_STRIDE,
                                            fl_pos1);
                 }
             }
@@ -732,7 +734,7 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
                 }
             } else if (!(a.dbg & 32)) {
                 // Candidate append, one entry per lane and round: a lane emits its lowest pending
-                // (query block, row) pair; the wave reserves the round's slots with ONE LDS atomic.
+                // (query block, row) pair; the round's slots follow the wave's own (scalar) fill count.
                 // Most lanes have nothing and most of the others exactly one pair, so a wave-tile
                 // usually takes a single round (the 16-way per-bit branching this replaces cost
                 // more than the MFMA loop's converts).
@@ -740,10 +742,8 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
                 for (;;) {
                     const unsigned long long m = __ballot(rem != 0u);
                     if (m == 0ull) break;
-                    const int first = __ffsll((long long)m) - 1;
-                    int base = 0;
-                    if (lane == first) base = lds_add_rtn(nb_addr + par * 4, __popcll(m));
-                    base = __builtin_amdgcn_readlane(base, first);
+                    const int base = wc[par];
+                    wc[par] = base + (int)__popcll(m);
                     if (rem != 0u) {
                         const int idx = __ffs(rem) - 1;      // = 4 b + e
                         float u = uv[0];
@@ -761,8 +761,8 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
                             rb = (idx & 3) == 3 ? rcv[3][3] : rb;
                             row = __float_as_int(rb);
                         }
-                        if (p < HALF) {
-                            lds_write3(buf_addr + par * (HALF * 12) + p * 12, (uint32_t)q, (uint32_t)row,
+                        if (p < WCAP) {
+                            lds_write3(wreg_addr + par * (WCAP * 12) + p * 12, (uint32_t)q, (uint32_t)row,
                                        __float_as_uint(u));
                         } else {
                             // burst beyond the buffer (e.g. a run of fresh rows that every query
@@ -782,14 +782,14 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
             const uint32_t ts3 = ts2;
             mma();
             const uint32_t ts4 = stamp();
-            if (MODE == CS_MODE_FILTER && fl_n > 0) {       // second step of the write-out (uniform)
+            if (MODE == CS_MODE_FILTER && fl_n > 0) {       // second step of the write-out (wave-uniform)
                 if (t + 2 >= seg) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 else if (wave == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GL) : "memory");   // reservations are older
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
-                const uint32_t eb = buf_addr + (par ^ 1) * (HALF * 12);
+                const uint32_t eb = wreg_addr + (par ^ 1) * (WCAP * 12);
 #pragma unroll
-                for (int u = 0; u < HALF / THREADS; ++u) {
-                    const int i = tid + u * THREADS;
+                for (int u = 0; u < EPL; ++u) {
+                    const int i = lane + u * 64;
                     const int pos = u == 0 ? fl_pos0 : fl_pos1;
                     if (i < fl_n && pos < a.cap) {
                         uint32_t eq, er, eu;
@@ -798,7 +798,7 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
                         a.cand_idx[(int64_t)eq * a.cap + pos] = (int32_t)er;
                     }
                 }
-                if (tid == 0) lds_write_i32(nb_addr + (par ^ 1) * 4, 0);   // seen by all after the next barrier
+                wc[par ^ 1] = 0;
             }
 
             const uint32_t ts5 = stamp();
@@ -819,9 +819,7 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (MODE == CS_MODE_FILTER) {                       // span end: both halves go out
-            const int n0 = __builtin_amdgcn_readfirstlane(lds_read_i32(nb_addr));
-            const int n1 = __builtin_amdgcn_readfirstlane(lds_read_i32(nb_addr + 4));
-            if (n0 > 0 || n1 > 0) flush_all(n0, n1);
+            if (wc[0] > 0 || wc[1] > 0) flush_all();
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
