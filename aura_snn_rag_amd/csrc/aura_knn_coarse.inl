@@ -111,6 +111,10 @@ __device__ __forceinline__ void glds4(const float* g, char* lds_wave_base) {
 #endif
 constexpr int CS_PF16 = AURA_CS_PF16;       // bf16-row kernels: fragment reads run this many k-steps ahead
 constexpr int CS_QA8 = 30;  // 8-wave kernels (48 fragments, 8 accumulators per wave)
+#ifndef AURA_CS_WFLUSH_DIV
+#define AURA_CS_WFLUSH_DIV 4
+#endif
+constexpr int CS_WFLUSH_DIV = AURA_CS_WFLUSH_DIV;   // a wave writes a stable half out once it holds capacity / this
 constexpr int CS_QA = 60;   // fragments (4 registers each) kept in AGPRs, next to the 16 accumulators
 // LDS accesses of the steady-state loop that are NOT the MFMA fragments go through inline asm:
 // hipcc puts "s_waitcnt vmcnt(0)" in front of an ordinary LDS access it cannot separate from an
@@ -445,7 +449,7 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
     // (by its own wave) once it holds WFLUSH entries; entries beyond WCAP go straight to the lists.
     constexpr int WCAP = CS_BUF / (2 * NW);                // 64 (8 waves) or 128 (4 waves)
     constexpr int EPL = WCAP / 64;                         // entries per lane and half in a write-out
-    constexpr int WFLUSH = WCAP / 4;
+    constexpr int WFLUSH = WCAP / CS_WFLUSH_DIV;
     const uint32_t cs_base = lds_addr(csmem);
     const uint32_t buf_addr = cs_base + NSLOT * SLOT_BYTES;
     const uint32_t wreg_addr = buf_addr + wave * (2 * WCAP * 12);
