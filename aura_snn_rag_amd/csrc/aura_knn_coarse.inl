@@ -1085,8 +1085,11 @@ inline int dispatch_coarse(const CoarseArgs& a, int mode, int grid, hipStream_t 
     // bf16-row kernels run 8 waves per workgroup (two per SIMD) unless AURA_CS_WAVES4 is set (A/B runs)
     static const bool w4 = getenv("AURA_CS_WAVES4") != nullptr;
     if (a.bank16 && a.probe_mask) {
-        // (the masked epilogue's mask words do not fit the 256-register budget at D = 768: its 8-wave
-        // form spills fragments inside the tile loop, so this mode keeps one wave per SIMD)
+        if (!w4) {
+            if (ks <= 8) return launch_coarse<8, true, true, 8>(a, mode, grid, s);
+            if (ks <= 16) return launch_coarse<16, true, true, 8>(a, mode, grid, s);
+            return launch_coarse<24, true, true, 8>(a, mode, grid, s);
+        }
         if (ks <= 8) return launch_coarse<8, true, true>(a, mode, grid, s);
         if (ks <= 16) return launch_coarse<16, true, true>(a, mode, grid, s);
         return launch_coarse<24, true, true>(a, mode, grid, s);
