@@ -1,4 +1,5 @@
-"""Randomised agreement sweep: inverted lists on the two-stage scan vs the masked fp32 scan, bit for bit.
+"""Randomised agreement sweep: inverted lists on the two-stage scan and the masked two-stage scan vs the
+masked fp32 scan, bit for bit.
 python tools/ivf2_fuzz.py [cases] [seed]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -39,12 +40,19 @@ def sweep(cases=30, seed=0, dev=None, verbose=True):
         s1, r1, o1 = ops.knn_search_ivf2(bank, inv, meta, q, k, now, cent, 8, sshadow, srows, pad_off, lens)
         flag = int(o1.item())
         s0, r0 = ops.knn_search(bank, inv, meta, q, k, now, centroids=cent, nprobe=8, fp32_scan=True)
+        # third path: the masked two-stage scan over the (unsorted) bf16 shadow
+        shadow = torch.empty(N, D, dtype=torch.bfloat16, device=dev); ops.bank_shadow_update(bank, shadow)
+        s2, r2 = ops.knn_search(bank, inv, meta, q, k, now, centroids=cent, nprobe=8, shadow=shadow)
+        masked_ok = bool(torch.equal(r0, r2) and torch.equal(s0, s2))
+        del shadow
         if flag:
             okq = (r0 == r1).all(1)
             ok = bool(torch.equal(s0[okq], s1[okq]))        # overflowed queries may differ, the rest must not
             note = f"overflow flag {flag}, {int((~okq).sum())} queries affected"
         else:
             ok = bool(torch.equal(r0, r1) and torch.equal(s0, s1)); note = ""
+        if not masked_ok: note += " | masked two-stage MISMATCH"
+        ok = ok and masked_ok
         if verbose or not ok:
             print(f"case {c}: N={N} D={D} nq={nq} k={k} ncent={ncent}: {'ok' if ok else 'MISMATCH'} {note}", flush=True)
         bad += 0 if ok else 1
