@@ -38,8 +38,8 @@ MFMA_F32_PEAK_TF = 157.3    # fp32 matrix peak (v_mfma_f32_32x32x2_f32), dense
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--bank-rows", type=int, default=100_000)
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--nq", type=int, default=256)
