@@ -215,15 +215,18 @@ __device__ __forceinline__ uint32_t cs_swz32(uint32_t row) {
 #endif
 }
 
-template <bool QA, bool LAST>
+template <bool QA, bool LAST, bool PAD>
 __device__ __forceinline__ void mfma_bf16_q(f32x4v& acc, const bf16x8v& af, const bf16x8v& q) {
-    // s_nop 1 in front: two wait states between a VALU write of an operand register (the bf16
-    // convert, or a register the compiler reloaded just before this statement) and the MFMA reading
-    // it; they elapse while the previous MFMA still occupies the pipe.
+    // PAD: s_nop 1 in front = the two wait states between a VALU write of an operand register and the
+    // MFMA reading it (hipcc pads nothing inside inline asm).  The fp32-row kernels need it: their A
+    // fragment comes out of v_cvt_pk_bf16_f32 right before.  The bf16-row kernels run without: the A
+    // fragment comes from ds_read_b128 behind an s_waitcnt, the query fragments are never rewritten and
+    // the accumulator set-up is several instructions away -- tools/check_mfma_hazards.py (a CPU test)
+    // verifies exactly that on the generated code of every build (0.6 ns of the 8.2 ns per MFMA).
     // LAST (the tile's final k-step): 12 wait states behind the MFMA, INSIDE the statement, because
     // the compiler may read or move the accumulator right after it (it has no idea this is an MFMA).
     // AURA_CS_EXP_*: timing experiments only (tools/build_variant.sh; results are wrong with them)
-#ifdef AURA_CS_EXP_NONOP
+#if defined(AURA_CS_EXP_NONOP)
 #define AURA_NOP1 ""
 #else
 #define AURA_NOP1 "s_nop 1\n\t"
@@ -233,16 +236,25 @@ __device__ __forceinline__ void mfma_bf16_q(f32x4v& acc, const bf16x8v& af, cons
 #else
 #define AURA_MFMA "v_mfma_f32_16x16x32_bf16 "
 #endif
-    if constexpr (QA && LAST)
-        asm volatile(AURA_NOP1 AURA_MFMA "%0, %1, %2, %0\n\ts_nop 7\n\ts_nop 4"
-                     : "+a"(acc) : "v"(af), "a"(q));
-    else if constexpr (QA)
-        asm volatile(AURA_NOP1 AURA_MFMA "%0, %1, %2, %0" : "+a"(acc) : "v"(af), "a"(q));
-    else if constexpr (LAST)
-        asm volatile(AURA_NOP1 AURA_MFMA "%0, %1, %2, %0\n\ts_nop 7\n\ts_nop 4"
-                     : "+a"(acc) : "v"(af), "v"(q));
-    else
-        asm volatile(AURA_NOP1 AURA_MFMA "%0, %1, %2, %0" : "+a"(acc) : "v"(af), "v"(q));
+    if constexpr (PAD) {
+        if constexpr (QA && LAST)
+            asm volatile(AURA_NOP1 AURA_MFMA "%0, %1, %2, %0\n\ts_nop 7\n\ts_nop 4" : "+a"(acc) : "v"(af), "a"(q));
+        else if constexpr (QA)
+            asm volatile(AURA_NOP1 AURA_MFMA "%0, %1, %2, %0" : "+a"(acc) : "v"(af), "a"(q));
+        else if constexpr (LAST)
+            asm volatile(AURA_NOP1 AURA_MFMA "%0, %1, %2, %0\n\ts_nop 7\n\ts_nop 4" : "+a"(acc) : "v"(af), "v"(q));
+        else
+            asm volatile(AURA_NOP1 AURA_MFMA "%0, %1, %2, %0" : "+a"(acc) : "v"(af), "v"(q));
+    } else {
+        if constexpr (QA && LAST)
+            asm volatile(AURA_MFMA "%0, %1, %2, %0\n\ts_nop 7\n\ts_nop 4" : "+a"(acc) : "v"(af), "a"(q));
+        else if constexpr (QA)
+            asm volatile(AURA_MFMA "%0, %1, %2, %0" : "+a"(acc) : "v"(af), "a"(q));
+        else if constexpr (LAST)
+            asm volatile(AURA_MFMA "%0, %1, %2, %0\n\ts_nop 7\n\ts_nop 4" : "+a"(acc) : "v"(af), "v"(q));
+        else
+            asm volatile(AURA_MFMA "%0, %1, %2, %0" : "+a"(acc) : "v"(af), "v"(q));
+    }
 }
 
 // Per-call preparation for the two-stage path, one launch:
@@ -644,11 +656,11 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
 #pragma unroll
                 for (int b = 0; b < QB; ++b) {
                     if (b * KS + s < QA) {
-                        if (s == KS - 1) mfma_bf16_q<true, true>(acc[b], af, qf[b][s]);
-                        else mfma_bf16_q<true, false>(acc[b], af, qf[b][s]);
+                        if (s == KS - 1) mfma_bf16_q<true, true, !SRC16>(acc[b], af, qf[b][s]);
+                        else mfma_bf16_q<true, false, !SRC16>(acc[b], af, qf[b][s]);
                     } else {
-                        if (s == KS - 1) mfma_bf16_q<false, true>(acc[b], af, qf[b][s]);
-                        else mfma_bf16_q<false, false>(acc[b], af, qf[b][s]);
+                        if (s == KS - 1) mfma_bf16_q<false, true, !SRC16>(acc[b], af, qf[b][s]);
+                        else mfma_bf16_q<false, false, !SRC16>(acc[b], af, qf[b][s]);
                     }
                 }
                 // the epilogue's row constants are fetched behind the last two k-steps
