@@ -45,20 +45,23 @@ SIGNATURES = {
     "aura_knn_ivf_workspace_bytes": (I64, [I64, I, I]),
     "aura_knn_search_ivf": (I, [P, P, P, P, F, I64, I64, I64, I, P, I, P, P, P, I, I32, P, P, P, I64, P, P]),
     "aura_topk_merge": (I, [P, P, I, I64, I, P, P, P]),
-    "aura_bank_gather": (I, [P, P, P, I64, I64, P]),
+    "aura_bank_gather": (I, [P, I64, P, P, I64, I64, P]),
     "aura_kmeans_assign": (I, [P, P, P, P, I64, I64, I, P]),
-    "aura_kmeans_update": (I, [P, P, P, P, P, I64, I64, I, I, P]),
+    "aura_kmeans_means_workspace_bytes": (I64, [I64, I64, I]),
+    "aura_kmeans_segment_means": (I, [P, P, P, P, P, I64, I64, I64, I, P]),
+    "aura_kmeans_commit": (I, [P, P, P, P, I64, I, P]),
     "aura_addition_linear": (I, [P, P, P, P, I64, I64, I64, P]),
     "aura_gif_train_forward": (I, [P, P, P, P, P, P, F, I, F, F, I64, I64, I64, P]),
     "aura_gif_backward": (I, [P, P, P, P, P, P, F, I, F, F, I64, I64, I64, P]),
     "aura_lif_train_forward": (I, [P, P, P, P, P, P, P, I64, I64, P]),
     "aura_lif_backward": (I, [P, P, P, P, P, P, P, P, P, I64, I64, P]),
     "aura_gif_prosody_run": (I, [P, P, P, P, P, F, I, F, F, F, I64, I64, I64, P]),
-    "aura_bank_shadow_update": (I, [P, P, P, I64, I64, I64, P]),
-    "aura_knn_search_shadow": (I, [P, P, P, P, P, F, I64, I64, I64, I, I32, P, P, P, I64, I, P, P, I, P]),
+    "aura_bank_shadow_update": (I, [P, P, P, P, P, I64, I64, I64, P]),
+    "aura_knn_search_shadow": (I, [P, P, P, P, P, P, F, I64, I64, I64, I, I32, P, P, P, I64, I, P, P, I, P]),
     "aura_knn_ivf2_workspace_bytes": (I64, [I64, I64, I]),
-    "aura_bank_shadow_sorted": (I, [P, P, P, I64, I64, P]),
-    "aura_knn_search_ivf2": (I, [P, P, P, P, P, P, P, I64, I64, P, F, I64, I64, I, P, I, I32, P, P, P, I64, P, P]),
+    "aura_bank_shadow_sorted": (I, [P, P, P, P, P, P, I64, I64, P]),
+    "aura_ivf2_append": (I, [P, P, P, P, I64, I64, P, P, P, P, P, P, P, P]),
+    "aura_knn_search_ivf2": (I, [P, P, P, P, P, P, P, P, I64, I64, P, F, I64, I64, I, P, I, I32, P, P, P, I64, P, P]),
     "aura_profile_begin": (I, [I]),
     "aura_profile_end": (I, [P, I]),
     "aura_profile_last_scan": (I, [P, P]),

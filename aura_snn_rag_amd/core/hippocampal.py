@@ -30,6 +30,7 @@ from __future__ import annotations
 
 import time
 from dataclasses import dataclass, field
+from collections.abc import Mapping
 from typing import Any, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -53,11 +54,54 @@ class EpisodicMemory:
     strength: float = 1.0
 
 
+class _EpisodicView(Mapping):
+    """``episodic_memories`` of the reference (``:235-239``: a dict id -> EpisodicMemory) without one
+    Python object per write: records are built on access from ``id_to_idx`` and the per-slot write
+    times.  Read-only; same keys, ``len`` and iteration order as the reference's dict."""
+
+    def __init__(self, owner: "HippocampalFormation"):
+        self._o = owner
+
+    def __getitem__(self, mid: str) -> EpisodicMemory:
+        slot = self._o.id_to_idx[mid]
+        return EpisodicMemory(memory_id=mid, feature_idx=slot, timestamp=float(self._o._slot_time[slot]))
+
+    def __iter__(self):
+        return iter(self._o.id_to_idx)
+
+    def __len__(self) -> int:
+        return len(self._o.id_to_idx)
+
+    def __contains__(self, mid) -> bool:
+        return mid in self._o.id_to_idx
+
+
+class _IvfState:
+    """Inverted lists of the centroid index in the layout ``aura_knn_search_ivf2`` streams: a
+    list-sorted bf16 shadow with ``slack`` free entries behind every list, so that writes are
+    appended in place (``aura_ivf2_append``) and the lists are re-packed only when the centroids
+    are rebuilt or the slack is used up."""
+
+    def __init__(self, max_rows: int, D: int, slack: int, device):
+        self.slack = slack
+        self.n_alloc = ops.ivf2_alloc_rows(max_rows, slack)
+        self.sorted_bf16 = torch.empty(self.n_alloc, D, dtype=torch.bfloat16, device=device)
+        self.sorted_rows = torch.empty(self.n_alloc, dtype=torch.int32, device=device)
+        self.pad_off = torch.zeros(257, dtype=torch.int32, device=device)
+        self.list_len = torch.zeros(256, dtype=torch.int32, device=device)
+        self.pos_of_row = torch.full((max_rows,), -1, dtype=torch.int32, device=device)
+        self.flag = torch.zeros(1, dtype=torch.int32, device=device)
+        self.n_sorted = 16            # sorted rows in use (host-side bound, a multiple of 16)
+        self.appended = 0             # rows appended since the last re-pack
+        self.valid = False
+
+
 class HippocampalFormation(nn.Module):
     # above this many rows the inverted lists (each probed list read once per batch) beat a masked
     # pass over every row
     MASKED_SCAN_MAX_ROWS = 250_000
     MASKED_SCAN_MAX_QUERIES = 512      # beyond: every 256 queries cost another pass over all rows
+    SHADOW_MIN_ROWS = 8192             # below: the all-fp32 scan (no prefilter)
 
     def __init__(self,
                  spatial_dimensions: int = 2,
@@ -97,15 +141,18 @@ class HippocampalFormation(nn.Module):
         # build-side: 1/max(||row||, 1e-12), refreshed by every write (not part of the state_dict)
         self.register_buffer('_inv_norm', torch.zeros(max_memories, device=dev), persistent=False)
         self._norms_valid_upto = 0
-        # build-side: bf16 copy of the rows for the exact recall's prefilter (half the bytes to
-        # stream; results unchanged).  Allocated on the first full-scan recall of >= 8192 rows.
+        # build-side: bf16 copy of the NORMALISED rows for the exact recall's prefilter (half the bytes
+        # to stream; results unchanged) and each row's rounding residual (its part of the prefilter's
+        # error bound).  Allocated on the first full-scan recall of >= SHADOW_MIN_ROWS rows.
         self._use_shadow = bool(bf16_shadow) and feature_dim % 8 == 0 and feature_dim <= 768
         self._shadow = None
+        self._rho = None
         self._shadow_valid_upto = 0
 
-        self.episodic_memories: Dict[str, EpisodicMemory] = {}
         self.id_to_idx: Dict[str, int] = {}
         self._idx_to_id: List[Optional[str]] = [None] * max_memories  # dense reverse map
+        self._slot_time = np.zeros(max_memories, dtype=np.float64)     # host clock of each slot's last write
+        self.episodic_memories = _EpisodicView(self)
         # bulk-ingested rows get implicit ids "<prefix><n>" resolved on lookup: (slot0, slot1, prefix, n0)
         self._implicit_ids: List[Tuple[int, int, str, int]] = []
 
@@ -119,10 +166,11 @@ class HippocampalFormation(nn.Module):
         self.register_buffer('centroids', torch.zeros(self.centroids_k, feature_dim, device=dev))
         self.register_buffer('centroid_counts', torch.zeros(self.centroids_k, device=dev))
         self._index_ready = False
-        # inverted lists (row ids grouped by centroid id), derived lazily from memory_metadata[:, 2]
-        self._lists = None            # (list_rows, list_off, list_len) or None
-        self._lists2 = None           # (list-sorted bf16 shadow, sorted row ids, padded list starts)
-        self._lists_count = -1        # memory_count the lists were built for
+        # inverted lists of the centroid index, derived from memory_metadata[:, 2]:
+        self._ivf: Optional[_IvfState] = None     # list-sorted bf16 shadow, kept current by the writes
+        self._ivf_pending = None                  # (order, seg_off) left by rebuild_centroids for the next re-pack
+        self._lists = None                        # fp32 fallback lists (list_rows, list_off, list_len, longest)
+        self._lists_dirty = True
 
         if overflow not in ('reference', 'fifo'):
             raise ValueError("overflow must be 'reference' or 'fifo'")
@@ -134,61 +182,113 @@ class HippocampalFormation(nn.Module):
     def _invalidate_norms(self) -> None:
         self._norms_valid_upto = 0
         self._shadow_valid_upto = 0
-        self._lists = None
-        self._lists2 = None
+        self._invalidate_lists()
 
-    def _ensure_sorted_shadow(self):
-        """(sorted bf16 rows, sorted row ids, padded list starts) for the two-stage inverted-list
-        recall, rebuilt with the lists; None when the shadow does not apply."""
-        if not self._use_shadow or self.memory_count < 8192 or not self.memory_features.is_cuda:
-            return None
-        list_rows, list_off, list_len, _ = self._ensure_lists()
-        if getattr(self, "_lists2", None) is None:
-            srows, pad_off = ops.ivf2_layout(list_rows, list_off, list_len)
-            self._lists2 = (ops.bank_shadow_sorted(self.memory_features, srows), srows, pad_off)
-        return self._lists2
+    def _invalidate_lists(self) -> None:
+        self._lists_dirty = True
+        self._ivf_pending = None
+        if self._ivf is not None:
+            self._ivf.valid = False
+
+    def _ensure_rho(self) -> torch.Tensor:
+        dev = self.memory_features.device
+        if self._rho is None or self._rho.device != dev:
+            self._rho = torch.zeros(self.max_memories, dtype=torch.float32, device=dev)
+            self._shadow_valid_upto = 0
+            if self._ivf is not None:
+                self._ivf.valid = False
+        return self._rho
+
+    def _shadow_applies(self) -> bool:
+        return self._use_shadow and self.memory_count >= self.SHADOW_MIN_ROWS and self.memory_features.is_cuda
 
     def _ensure_shadow(self):
-        """bf16 shadow of rows [0, memory_count), or None when it does not apply."""
-        if not self._use_shadow or self.memory_count < 8192 or not self.memory_features.is_cuda:
+        """bf16 shadow of rows [0, memory_count) (+ their residual norms), or None when it does not apply."""
+        if not self._shadow_applies():
             return None
+        self._ensure_norms()
+        rho = self._ensure_rho()
         if self._shadow is None or self._shadow.device != self.memory_features.device:
             self._shadow = torch.empty(self.memory_features.shape, dtype=torch.bfloat16,
                                        device=self.memory_features.device)
             self._shadow_valid_upto = 0
         if self._shadow_valid_upto < self.memory_count:
             lo = self._shadow_valid_upto
-            ops.bank_shadow_update(self.memory_features, self._shadow, lo, self.memory_count - lo)
+            ops.bank_shadow_update(self.memory_features, self._inv_norm, self._shadow, rho, lo,
+                                   self.memory_count - lo)
             self._shadow_valid_upto = self.memory_count
         return self._shadow
 
-    def _shadow_after_write(self, slot_t: torch.Tensor, lo: int, hi: int) -> None:
-        """Keep the shadow current for rows just written (only the part it already covers)."""
-        if self._shadow is None or self._shadow_valid_upto <= lo:
-            return                                  # those rows get converted by _ensure_shadow
-        ops.bank_shadow_update(self.memory_features, self._shadow, slots=slot_t)
-        self._shadow_valid_upto = max(self._shadow_valid_upto, min(hi + 1, self.memory_count))
+    def _shadow_after_write(self, slot_t: torch.Tensor, lo: int, hi: int, contiguous: bool) -> None:
+        """Keep the shadow current for the rows just written.  The watermark ``_shadow_valid_upto`` only
+        ever moves over rows that HAVE been converted: a contiguous append that starts at the watermark
+        advances it; rows below it are converted in place; anything else is left to ``_ensure_shadow``
+        (which converts [watermark, count) before the next recall)."""
+        if self._shadow is None:
+            return
+        upto = self._shadow_valid_upto
+        if contiguous and lo == upto:
+            ops.bank_shadow_update(self.memory_features, self._inv_norm, self._shadow, self._rho, lo, hi + 1 - lo)
+            self._shadow_valid_upto = hi + 1
+        elif lo < upto:
+            below = slot_t if hi < upto else slot_t[slot_t < upto]
+            ops.bank_shadow_update(self.memory_features, self._inv_norm, self._shadow, self._rho, slots=below.contiguous())
 
     def _ensure_lists(self):
-        """Inverted lists for the IVF recall: row ids of [0, memory_count) sorted by centroid id
-        (rows with id < 0 first), list starts and lengths -- a stable sort + bincount on the
-        device, redone only after a write / rebuild changed the assignments."""
+        """fp32 inverted lists (the fallback of the two-stage lists): row ids of [0, memory_count) sorted
+        by centroid id (rows with id < 0 first), list starts and lengths -- a stable sort + bincount on
+        the device, redone only after a write / rebuild changed the assignments."""
         n = self.memory_count
-        if self._lists is None or self._lists_count != n:
-            cids = self.memory_metadata[:n, 2].to(torch.int32)
-            order = torch.sort(cids, stable=True).indices.to(torch.int32)
-            valid = cids >= 0
-            lens = torch.bincount(cids.clamp(min=0).long(), weights=valid.to(torch.float32),
-                                  minlength=256)[:256].to(torch.int32)
-            n_neg = (n - valid.sum()).to(torch.int32).reshape(1)
-            off = torch.cat([n_neg, n_neg + torch.cumsum(lens, 0).to(torch.int32)]).contiguous()
+        if self._lists is None or self._lists_dirty or self._lists[4] != n:
+            order, seg_off = ops.group_by_cluster(self.memory_metadata[:n, 2], 256)
+            lens = (seg_off[1:] - seg_off[:-1]).contiguous()
             # slots per query: no query can collect more rows than the 8 longest lists hold
             # (one host read per list rebuild, not per recall)
             longest = int(torch.topk(lens, min(8, lens.numel())).values.sum().item())
-            self._lists = (order.contiguous(), off, lens.contiguous(), longest)
-            self._lists_count = n
-            self._lists2 = None                       # list-sorted bf16 shadow: built on demand
-        return self._lists
+            self._lists = (order, seg_off, lens, longest, n)
+            self._lists_dirty = False
+        return self._lists[:4]
+
+    def _ensure_ivf(self) -> Optional[_IvfState]:
+        """The list-sorted bf16 shadow for the two-stage inverted-list recall (re-packed only after a
+        centroid rebuild or when the slack behind the lists is used up); None when it does not apply."""
+        if not self._shadow_applies():
+            return None
+        self._ensure_norms()
+        rho = self._ensure_rho()
+        slack = ops.ivf2_slack(self.centroids_update_interval)
+        st = self._ivf
+        D = self.memory_features.shape[1]
+        if st is None or st.sorted_bf16.device != self.memory_features.device or st.slack != slack:
+            st = self._ivf = _IvfState(self.max_memories, D, slack, self.memory_features.device)
+        if not st.valid:
+            n = self.memory_count
+            if self._ivf_pending is not None and self._ivf_pending[0].numel() == n:
+                order, seg_off = self._ivf_pending
+            else:
+                order, seg_off = ops.group_by_cluster(self.memory_metadata[:n, 2], 256)
+            self._ivf_pending = None
+            ops.ivf2_layout(order, seg_off, slack, st.sorted_rows, st.pad_off, st.list_len)
+            st.n_sorted = min(st.n_alloc, ops.ivf2_alloc_rows(n, slack))
+            st.pos_of_row.fill_(-1)
+            ops.bank_shadow_sorted(self.memory_features, self._inv_norm, st.sorted_rows, st.sorted_bf16, rho,
+                                   st.pos_of_row, st.n_sorted)
+            st.appended = 0
+            st.valid = True
+        return st
+
+    def _ivf_after_write(self, uniq_slots: torch.Tensor, n_rows: int) -> None:
+        """Append the rows just written to their lists (their centroid ids are in the metadata)."""
+        st = self._ivf
+        if st is None or not st.valid:
+            return
+        if st.appended + n_rows > st.slack or self._rho is None:
+            st.valid = False                       # slack used up: re-pack at the next recall
+            return
+        ops.ivf2_append(self.memory_features, self._inv_norm, self.memory_metadata, uniq_slots, st.sorted_bf16,
+                        st.sorted_rows, st.pad_off, st.list_len, st.pos_of_row, self._rho, st.flag)
+        st.appended += n_rows
+        st.n_sorted = min(st.n_alloc, ops.ivf2_alloc_rows(self.memory_count, st.slack))
 
     def _apply(self, fn, *a, **k):  # keep self.device / current_location in step with .to()
         out = super()._apply(fn, *a, **k)
@@ -202,10 +302,9 @@ class HippocampalFormation(nn.Module):
             self._norms_valid_upto = self.memory_count
 
     def refresh_norms(self) -> None:
-        """Recompute the cached row norms and drop the bf16 shadow (call after writing
-        ``memory_features`` directly)."""
-        self._norms_valid_upto = 0
-        self._shadow_valid_upto = 0
+        """Recompute the cached row norms and drop the bf16 shadows (call after writing
+        ``memory_features`` or ``memory_metadata[:, 2]`` directly)."""
+        self._invalidate_norms()
         if self.memory_count:
             self._ensure_norms()
 
@@ -250,44 +349,77 @@ class HippocampalFormation(nn.Module):
 
     # ------------------------------------------------------------------ write
     def _plan_slots(self, n: int):
-        """Slots for the next n writes plus the counters they leave behind (nothing is mutated
-        until the kernel launch has been accepted)."""
-        count, cursor, slots = self.memory_count, self._write_cursor, []
-        for _ in range(n):
-            if count >= self.max_memories:
-                if self._overflow == 'reference':
-                    slots.append(count % self.max_memories)   # == 0, as the reference (:200-202)
-                else:
-                    slots.append(cursor % self.max_memories)
-                    cursor += 1
+        """Slots (int64 ndarray) for the next n writes, how many of them append, and the counters they
+        leave behind (nothing is mutated until the kernel launch has been accepted)."""
+        M, count, cursor = self.max_memories, self.memory_count, self._write_cursor
+        n_app = min(n, max(M - count, 0))
+        slots = np.empty(n, dtype=np.int64)
+        slots[:n_app] = np.arange(count, count + n_app, dtype=np.int64)
+        rest = n - n_app
+        if rest:
+            if self._overflow == 'reference':
+                slots[n_app:] = 0                  # count % max_memories with count == max_memories (:200-202)
             else:
-                slots.append(count)
-                count += 1
-        return slots, count, cursor
+                slots[n_app:] = (cursor + np.arange(rest, dtype=np.int64)) % M
+                cursor += rest
+        return slots, n_app, count + n_app, cursor
+
+    @staticmethod
+    def _last_occurrences(slots: np.ndarray, n_app: int) -> Optional[np.ndarray]:
+        """Indices (ascending) of the last write to every distinct slot, or None if all are distinct."""
+        if slots.size - n_app <= 0 or (slots.size - n_app == 1 and n_app == 0):
+            return None
+        _, first_rev = np.unique(slots[::-1], return_index=True)
+        if first_rev.size == slots.size:
+            return None
+        return np.sort(slots.size - 1 - first_rev)
+
+    def _after_write(self, slot_t: torch.Tensor, uniq_t: torch.Tensor, slots: np.ndarray, c0: int, n_app: int) -> None:
+        """Derived state after a write: the appended run [c0, c0 + n_app) and the overwritten slots."""
+        if n_app and self._norms_valid_upto >= c0:     # the kernel refreshed 1/||row|| of the written slots
+            self._norms_valid_upto = max(self._norms_valid_upto, c0 + n_app)
+        if self._shadow is not None:
+            if n_app:
+                self._shadow_after_write(slot_t[:n_app], c0, c0 + n_app - 1, contiguous=True)
+            if slots.size > n_app:
+                over = uniq_t[uniq_t < c0] if n_app else uniq_t
+                if over.numel():
+                    self._shadow_after_write(over, int(slots[n_app:].min()), int(slots[n_app:].max()), contiguous=False)
+        self._lists_dirty = True
+        self._ivf_pending = None
+        self._ivf_after_write(uniq_t, int(uniq_t.numel()))
 
     def _write_rows(self, ids: Sequence[str], feats: torch.Tensor, now: float) -> None:
         """Write a run of rows that contains no centroid-rebuild boundary."""
-        slots, new_count, new_cursor = self._plan_slots(len(ids))
-        slot_t = torch.tensor(slots, dtype=torch.int64, device=self.device)
+        slots, n_app, new_count, new_cursor = self._plan_slots(len(ids))
+        c0 = self.memory_count
+        slot_t = torch.from_numpy(slots).to(self.device)
         online = self.use_centroid_index and self._index_ready
         eff_k = min(self.centroids_k, self.centroids.shape[0])
+        # A batch that overwrites may name a slot more than once (a full bank in the reference's mode
+        # sends every write to slot 0): the last write wins, as in the reference's sequential loop.  The
+        # serial centroid kernel walks the rows in order; the parallel kernel gets the survivors only.
+        keep = self._last_occurrences(slots, n_app)
+        uniq_t = slot_t if keep is None else slot_t[torch.from_numpy(keep).to(self.device)]
+        if keep is not None and not online:
+            feats_w, slot_w = feats[torch.from_numpy(keep).to(self.device)].contiguous(), uniq_t.contiguous()
+        else:
+            feats_w, slot_w = feats, slot_t
         ops.bank_write(self.memory_features, self.memory_locations, self.memory_metadata,
-                       self._inv_norm, feats, slot_t,
+                       self._inv_norm, feats_w, slot_w,
                        self.current_location.to(device=self.device, dtype=torch.float32).contiguous(),
                        now,
                        centroids=self.centroids if online else None,
                        centroid_counts=self.centroid_counts if online else None,
                        eff_k=eff_k if online else 0)
         self.memory_count, self._write_cursor = new_count, new_cursor
-        self._lists = None
-        lo, hi = min(slots), max(slots)
-        if self._norms_valid_upto >= lo:      # the kernel refreshed 1/||row|| of the written slots
-            self._norms_valid_upto = max(self._norms_valid_upto, hi + 1)
-        self._shadow_after_write(slot_t, lo, hi)
-        stamp = time.time()
-        for mid, slot in zip(ids, slots):
-            self.episodic_memories[mid] = EpisodicMemory(memory_id=mid, feature_idx=slot, timestamp=stamp)
-            self.id_to_idx[mid] = slot
+        self._after_write(slot_t, uniq_t.contiguous(), slots, c0, n_app)
+        self._slot_time[slots] = time.time()
+        slot_list = slots.tolist()
+        self.id_to_idx.update(zip(ids, slot_list))
+        if n_app:
+            self._idx_to_id[c0:c0 + n_app] = list(ids[:n_app])
+        for mid, slot in zip(ids[n_app:], slot_list[n_app:]):
             self._idx_to_id[slot] = mid
 
     def id_of_row(self, row: int) -> Optional[str]:
@@ -319,10 +451,8 @@ class HippocampalFormation(nn.Module):
                        self.current_location.to(device=self.device, dtype=torch.float32).contiguous(),
                        time.time())
         self.memory_count = s0 + n
-        self._lists = None
-        if self._norms_valid_upto >= s0:
-            self._norms_valid_upto = s0 + n
-        self._shadow_after_write(slot_t, s0, s0 + n - 1)
+        self._after_write(slot_t, slot_t, np.arange(s0, s0 + n, dtype=np.int64), s0, n)
+        self._slot_time[s0:s0 + n] = time.time()
         self._implicit_ids.append((s0, s0 + n, id_prefix, first_index))
         if rebuild and self.use_centroid_index and self.memory_count > self.centroids_k:
             self.rebuild_centroids()
@@ -367,7 +497,13 @@ class HippocampalFormation(nn.Module):
                      use_candidates: Optional[bool] = None, check_overflow: bool = True
                      ) -> Tuple[torch.Tensor, torch.Tensor]:
         """Batched recall: ``(scores [nq, k'], rows [nq, k'])`` with ``k' = min(k, count)``;
-        rows are bank row indices (int32), ``-1`` where a query has fewer than ``k'`` candidates."""
+        rows are bank row indices (int32), ``-1`` where a query has fewer than ``k'`` candidates.
+
+        ``check_overflow`` (default) reads one small tensor back per call (a host sync): the
+        prefilter's overflow flag (candidate lists that did not fit: the call is re-run on the fp32
+        path, same results) and, in candidate mode, whether some query was left without candidates
+        (it then falls back to the full scan, reference ``:269-270``).  Pass False only inside
+        latency-critical loops whose data is known to be well behaved."""
         if self.memory_count == 0:
             z = torch.empty(queries.shape[0], 0, device=self.device)
             return z, z.to(torch.int32)
@@ -389,37 +525,41 @@ class HippocampalFormation(nn.Module):
         if not cand:
             shadow = self._ensure_shadow() if q_loc is None else None
             return ops.knn_search(self.memory_features, self._inv_norm, self.memory_metadata, q, kk, now,
-                                  shadow=shadow, **kw)
+                                  shadow=shadow, rho=self._rho if shadow is not None else None, **kw)
         nprobe = min(8, self.centroids_k)
-        scores = rows = None
-        masked_ok = (q_loc is None and self.memory_count <= self.MASKED_SCAN_MAX_ROWS and
+        scores = rows = ovf = None
+        full_index = self.centroids.shape[0] == 256
+        masked_ok = (q_loc is None and full_index and self.memory_count <= self.MASKED_SCAN_MAX_ROWS and
                      q.shape[0] <= self.MASKED_SCAN_MAX_QUERIES)
         shadow = self._ensure_shadow() if masked_ok else None
-        lists2 = None
-        if shadow is None and q_loc is None and self.centroids.shape[0] == 256 and kk <= 256:
-            lists2 = self._ensure_sorted_shadow()
-        if lists2 is not None:
-            # large banks / large batches: inverted lists on the two-stage scan (every probed list is
-            # streamed once per 2048 queries from the list-sorted bf16 shadow; 1.9e6 retrievals/s at
-            # 1M x 768 vs 0.83e6 for the fp32 lists); same rows and score bits
-            sshadow, srows, pad_off = lists2
-            _, _, list_len, _ = self._ensure_lists()
-            scores, rows, ovf = ops.knn_search_ivf2(self.memory_features, self._inv_norm, self.memory_metadata,
-                                                    q, kk, now, self.centroids, nprobe, sshadow, srows,
-                                                    pad_off, list_len)
-            if check_overflow and int(ovf.item()) != 0:
-                scores = rows = None                  # candidate lists too long: fp32 lists below
-        if scores is not None:
-            pass
-        elif shadow is not None and self.centroids.shape[0] == 256:
+        if shadow is not None:
             # up to a few hundred thousand rows the candidate restriction is cheapest as probe masks
-            # inside the two-stage scan (one pass over the bf16 shadow; 0.17 vs 0.20 ms at 100k x 768,
+            # inside the two-stage scan (one pass over the bf16 shadow; 0.15 vs 0.20 ms at 100k x 768,
             # 256 queries); same rows and score bits as the inverted lists
-            scores, rows = ops.knn_search(self.memory_features, self._inv_norm, self.memory_metadata,
-                                          q, kk, now, centroids=self.centroids, nprobe=nprobe,
-                                          shadow=shadow, **kw)
-        elif q_loc is None and self.centroids.shape[0] == 256:
-            # inverted-list form: every probed list is streamed once per batch
+            scores, rows, ovf = ops.knn_search(self.memory_features, self._inv_norm, self.memory_metadata,
+                                               q, kk, now, centroids=self.centroids, nprobe=nprobe,
+                                               shadow=shadow, rho=self._rho, count=self.memory_count,
+                                               check_overflow=False, return_flag=True)
+        elif q_loc is None and full_index and kk <= 256:
+            ivf = self._ensure_ivf()
+            if ivf is not None:
+                # large banks / large batches: inverted lists on the two-stage scan (every probed list is
+                # streamed once per 2048 queries from the list-sorted bf16 shadow); same rows and score bits
+                scores, rows, ovf = ops.knn_search_ivf2(self.memory_features, self._inv_norm, self.memory_metadata,
+                                                        q, kk, now, self.centroids, nprobe, ivf.sorted_bf16,
+                                                        self._rho, ivf.sorted_rows, ivf.pad_off, ivf.list_len,
+                                                        n_sorted=ivf.n_sorted)
+        if check_overflow and scores is not None:
+            # ONE host read for both conditions: overflow of the two-stage lists, queries without candidates
+            empty = rows[:, 0] < 0
+            flags = torch.stack([(ovf if ovf is not None else empty.new_zeros(1, dtype=torch.int32))[0] != 0,
+                                 empty.any()]).tolist()
+            if flags[0]:
+                scores = rows = None                  # candidate lists too long: the fp32 paths below
+            elif not flags[1]:
+                return scores, rows
+        if scores is None and q_loc is None and full_index:
+            # fp32 inverted lists: every probed list is streamed once per batch
             list_rows, list_off, list_len, longest = self._ensure_lists()
             cap = ops.ivf_capacity(longest, kk)
             if cap is not None:               # else: lists too long for the two-level select
@@ -430,6 +570,8 @@ class HippocampalFormation(nn.Module):
         if scores is None:
             scores, rows = ops.knn_search(self.memory_features, self._inv_norm, self.memory_metadata,
                                           q, kk, now, centroids=self.centroids, nprobe=nprobe, **kw)
+        if not check_overflow:
+            return scores, rows
         # a query whose probed centroids own no rows falls back to the full scan (ref :269-270)
         empty = (rows[:, 0] < 0)
         if bool(empty.any()):
@@ -468,6 +610,7 @@ class HippocampalFormation(nn.Module):
                 "centroids_update_interval": self.centroids_update_interval,
                 "ids_by_slot": list(self._idx_to_id[:n]),
                 "id_to_idx": dict(self.id_to_idx),
+                "slot_time": self._slot_time[:n].tobytes(),            # float64 host clock per slot
                 "implicit_ids": list(self._implicit_ids)}
 
     def load_bank_state(self, state: Dict[str, Any]) -> None:
@@ -485,9 +628,9 @@ class HippocampalFormation(nn.Module):
         self.id_to_idx = dict(state.get("id_to_idx") or
                               {mid: i for i, mid in enumerate(state["ids_by_slot"]) if mid is not None})
         self._implicit_ids = [tuple(x) for x in state.get("implicit_ids", [])]
-        stamp = time.time()
-        self.episodic_memories = {mid: EpisodicMemory(memory_id=mid, feature_idx=i, timestamp=stamp)
-                                  for mid, i in self.id_to_idx.items()}
+        self._slot_time[:] = 0.0
+        st = state.get("slot_time")
+        self._slot_time[:n] = np.frombuffer(st, dtype=np.float64)[:n] if st is not None else time.time()
         self._invalidate_norms()
 
     def gather_features(self, rows: torch.Tensor) -> torch.Tensor:
@@ -507,7 +650,11 @@ class HippocampalFormation(nn.Module):
     def rebuild_centroids(self, perm: Optional[torch.Tensor] = None) -> None:
         """One Lloyd iteration from a random sample of rows (reference ``:345-377``).  The
         ``randperm`` is drawn from torch's global CPU generator exactly as the reference does on a
-        CPU device, so a seeded run reproduces its sample."""
+        CPU device, so a seeded run reproduces its sample.
+
+        assign (fp32 matrix cores) -> rows grouped by cluster (device sort) -> means as a segmented
+        reduction (the bank is read once) -> second assign -> counts + metadata; the second grouping
+        is kept for the next re-pack of the inverted lists."""
         if self.memory_count == 0 or not self.use_centroid_index:
             return
         n = self.memory_count
@@ -522,8 +669,10 @@ class HippocampalFormation(nn.Module):
         self.centroids.copy_(cent)          # rows >= k stay zero (ref :366-367)
         assign = ops.kmeans_assign(self.memory_features, self.centroids, n, k)
         counts = torch.zeros(self.centroids_k, device=self.device)
-        ops.kmeans_update(self.memory_features, assign, self.centroids, k, counts=counts,
-                          meta=self.memory_metadata, update_means=False)
+        order, seg_off = ops.kmeans_update(self.memory_features, assign, self.centroids, k, counts=counts,
+                                           meta=self.memory_metadata, update_means=False)
         self.centroid_counts = counts
         self._index_ready = True
-        self._lists = None
+        self._invalidate_lists()
+        if k == 256 and seg_off.numel() == 257:
+            self._ivf_pending = (order, seg_off)

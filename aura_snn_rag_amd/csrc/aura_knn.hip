@@ -25,6 +25,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <mutex>
+#include <set>
+#include <utility>
 #include <vector>
 #include <type_traits>
 
@@ -38,6 +41,21 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 inline int check_launch() { return hipGetLastError() == hipSuccess ? AURA_OK : AURA_E_LAUNCH; }
 inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (device, kernel); callable from any
+// host thread and for any device of the process
+inline int ensure_lds_attr(const void* fn, int bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<int, const void*>> done;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return AURA_E_LAUNCH;
+    std::lock_guard<std::mutex> g(mu);
+    if (done.count({dev, fn})) return AURA_OK;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess)
+        return AURA_E_LAUNCH;
+    done.insert({dev, fn});
+    return AURA_OK;
+}
 
 // order-preserving float -> uint32 (larger float <=> larger key); -0 < +0, NaN ends up extreme
 __device__ __forceinline__ uint32_t ord_key(float f) {
@@ -177,12 +195,13 @@ __global__ __launch_bounds__(256) void bank_decay_kernel(float* meta, float fact
 __global__ __launch_bounds__(256) void bank_gather_kernel(const float* __restrict__ bank,
                                                           const int32_t* __restrict__ idx,
                                                           float* __restrict__ out, int64_t n,
-                                                          int64_t D) {
+                                                          int64_t D, int64_t rows) {
     const int lane = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= n) return;
     const int32_t r = idx[i];
-    for (int64_t c = lane; c < D; c += 64) out[i * D + c] = r >= 0 ? bank[(int64_t)r * D + c] : 0.0f;
+    const bool ok = r >= 0 && r < rows;                      // anything else gathers zeros
+    for (int64_t c = lane; c < D; c += 64) out[i * D + c] = ok ? bank[(int64_t)r * D + c] : 0.0f;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1121,51 +1140,6 @@ __global__ __launch_bounds__(256) void row_norm2_kernel(const float* __restrict_
     if (lane == 0) out[row] = s;
 }
 
-// One workgroup per centroid: mean of the rows assigned to it (fixed summation order, so the
-// result is reproducible), count, and optionally the centroid id written to meta[row][2].
-// Empty clusters keep their centroid (hippocampal.py:362-363).
-__global__ __launch_bounds__(256) void kmeans_update_kernel(const float* __restrict__ bank,
-                                                            const int32_t* __restrict__ assign,
-                                                            float* centroids, float* counts,
-                                                            float* meta, int64_t N, int64_t D,
-                                                            int update_means) {
-    extern __shared__ __attribute__((aligned(16))) float s_acc[];  // [4][D]
-    __shared__ int s_cnt[4];
-    const int c = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float* acc = s_acc + (int64_t)wave * D;
-    for (int64_t j = lane; j < D; j += 64) acc[j] = 0.0f;
-    int cnt = 0;
-    // each wave walks a contiguous quarter of the rows in order; lanes cover the feature dim
-    const int64_t per = (N + 3) / 4;
-    const int64_t beg = wave * per, end = (beg + per) < N ? (beg + per) : N;
-    for (int64_t base = beg; base < end; base += 64) {
-        const int64_t r = base + lane;
-        const bool mine = r < end && assign[r] == c;
-        unsigned long long m = __ballot(mine);
-        if (mine && meta) meta[r * 4 + 2] = (float)c;
-        while (m) {
-            const int l = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            const int64_t row = base + l;
-            ++cnt;
-            if (update_means)
-                for (int64_t j = lane; j < D; j += 64) acc[j] += bank[row * D + j];
-        }
-    }
-    if (lane == 0) s_cnt[wave] = cnt;
-    __syncthreads();
-    const int total = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-    if (update_means && total > 0) {
-        const float inv = (float)total;
-        for (int64_t j = tid; j < D; j += 256) {
-            const float sum = ((s_acc[j] + s_acc[D + j]) + s_acc[2 * D + j]) + s_acc[3 * D + j];
-            centroids[(int64_t)c * D + j] = sum / inv;
-        }
-    }
-    if (tid == 0 && counts) counts[c] = (float)total;
-}
-
 // ------------------------------------------------------------------------------------------
 // Sample threshold.  The k-th largest of the per-group maxima of the sample (groups = 32-row
 // tiles) is a valid lower bound of the global k-th best score: the k largest group maxima are k
@@ -1469,6 +1443,7 @@ constexpr int CAND_CAP_MIN = 8192;      // filter-path candidate slots per query
 
 struct Workspace {
     float* inv_q;        // [qp]            (qp = queries per pass)
+    float* eq;           // [qp rounded up to 256] query parts of the two-stage error bound
     uint32_t* thr;       // [qp]
     int32_t* cnt;        // [qp][CNT_STRIDE]
     uint32_t* probe;     // [qp][8]
@@ -1511,6 +1486,7 @@ inline Workspace carve(void* base, int64_t N, int64_t nq, int k) {
     w.cap = cand_cap(N, k);
     w.cap2 = (int)align_up(((int64_t)w.cap + SEL_LDS_KEYS - 1) / SEL_LDS_KEYS * k, 64);
     w.inv_q = reinterpret_cast<float*>(take((int64_t)qb * 4));
+    w.eq = reinterpret_cast<float*>(take(((int64_t)qb + 255) / 256 * 256 * 4));
     w.thr = reinterpret_cast<uint32_t*>(take((int64_t)qb * 4));
     w.cnt = reinterpret_cast<int32_t*>(take((int64_t)qb * CNT_STRIDE * 4));
     w.probe = reinterpret_cast<uint32_t*>(take((int64_t)qb * 32));
@@ -1528,15 +1504,8 @@ inline Workspace carve(void* base, int64_t N, int64_t nq, int k) {
 }
 
 inline int launch_select(const SelectArgs& a, int64_t nchunks, int nq, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        // the final select keeps 8192 64-bit keys (64 KiB) + 9 KiB static in LDS
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(topk_select_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize,
-                                SEL_LDS_KEYS_HARD * 8) != hipSuccess)
-            return AURA_E_LAUNCH;
-        attr_set = true;
-    }
+    // the final select keeps 8192 64-bit keys (64 KiB) + 9 KiB static in LDS
+    if (ensure_lds_attr(reinterpret_cast<const void*>(topk_select_kernel), SEL_LDS_KEYS_HARD * 8)) return AURA_E_LAUNCH;
     if (a.chunk > SEL_LDS_KEYS_HARD || a.k > SEL_MAX_K) return AURA_E_INVAL;
     hipLaunchKernelGGL(topk_select_kernel, dim3((unsigned)nchunks, (unsigned)nq), dim3(SEL_THREADS),
                        (size_t)a.chunk * 8, s, a);
@@ -1594,16 +1563,13 @@ inline int device_cu_count() {
 // persistent FILTER scan for a 256-query block (a.n_items non-sample 32-row tiles)
 inline int launch_filter_v2(const ScanArgs& a, hipStream_t s) {
     const size_t lds = (size_t)2 * (256 + 128) * LDS_STRIDE * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    {
         const void* fns[4] = {reinterpret_cast<const void*>(knn_scan_filter_v2<true, true>),
                               reinterpret_cast<const void*>(knn_scan_filter_v2<true, false>),
                               reinterpret_cast<const void*>(knn_scan_filter_v2<false, true>),
                               reinterpret_cast<const void*>(knn_scan_filter_v2<false, false>)};
         for (const void* f : fns)
-            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-                return AURA_E_LAUNCH;
-        attr_set = true;
+            if (ensure_lds_attr(f, (int)lds)) return AURA_E_LAUNCH;
     }
     if (a.n_items <= 0) return AURA_OK;
     int64_t grid = device_cu_count();
@@ -1639,14 +1605,9 @@ inline int launch_refine_for(const RefineArgs& r, int nqb, int64_t D, int cus, h
         constexpr int ROWS = decltype(rows_tag)::value, KC = decltype(kc_tag)::value;
         size_t lds = (size_t)8 * ROWS * (KC + 4) * 4 + (size_t)Dpad * 4;
         if (lds < (size_t)RF_CAP * 12) lds = (size_t)RF_CAP * 12;
-        static bool attr_set = false;
-        if (!attr_set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(coarse_refine_kernel<ROWS, KC>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    8 * ROWS * (KC + 4) * 4 + 768 * 4) != hipSuccess)
-                return AURA_E_LAUNCH;
-            attr_set = true;
-        }
+        if (ensure_lds_attr(reinterpret_cast<const void*>(coarse_refine_kernel<ROWS, KC>),
+                            8 * ROWS * (KC + 4) * 4 + 768 * 4))
+            return AURA_E_LAUNCH;
         hipLaunchKernelGGL((coarse_refine_kernel<ROWS, KC>), dim3((unsigned)nqb), dim3(RF_THREADS), lds, s, r);
         return check_launch();
     };
@@ -1656,7 +1617,7 @@ inline int launch_refine_for(const RefineArgs& r, int nqb, int64_t D, int cus, h
 
 // Two-stage recall of one query pass (see aura_knn_coarse.inl).  Returns AURA_OK after queuing
 // sample scan -> threshold -> filter scan -> refine; the caller skips the fp32 pipeline.
-inline int run_coarse_pass(const float* bank, const uint16_t* bank16, const float* inv_norm,
+inline int run_coarse_pass(const float* bank, const uint16_t* bank16, const float* rho, const float* inv_norm,
                            const float* meta, const float* qptr, float now, int64_t N, int64_t D, int nqb, int k,
                            int32_t idx_base, float* out_scores, int32_t* out_idx,
                            const Workspace& w, int32_t* overflow_out, bool reset_flag,
@@ -1679,17 +1640,21 @@ inline int run_coarse_pass(const float* bank, const uint16_t* bank16, const floa
     // per-call preparation: bf16 query fragments + 1/||q|| (+ overflow-flag reset), row constants
     const int KS = D <= 256 ? 8 : (D <= 512 ? 16 : 24);
     const int64_t nq_pad = ((int64_t)nqb + 255) / 256 * 256;
-    const float e_cos = 0.00390625f * (1.0f + 0.001953125f) + 2.0f * (float)D * 5.9604645e-8f + 1e-5f;
+    // error bound of the bf16 scores (aura_knn_coarse.inl): E_fix for the accumulation, E_worst for
+    // rows rounded on the fly; with the shadow the rows' and queries' own residual norms
+    const float e_fix = 2.0f * (float)D * 5.9604645e-8f + 1e-5f;
+    const float e_cos = 0.0078125f * (1.0f + 0.001953125f) + e_fix;
+    // the shadow is only usable when its rows are 16-byte aligned and its error norms are known
+    const bool use16 = bank16 && rho && (D & 7) == 0 && (reinterpret_cast<uintptr_t>(bank16) & 15) == 0;
     const int qblocks = (int)(nq_pad / 4);
     hipLaunchKernelGGL(coarse_prep_kernel, dim3((unsigned)(qblocks + (N + 255) / 256)), dim3(256), 0, s,
-                       qptr, (int64_t)nqb, nq_pad, D, KS, w.qhat, w.inv_q,
-                       reset_flag ? overflow_out : nullptr, qblocks, meta, inv_norm, N, now, e_cos,
-                       w.rowc);
+                       qptr, (int64_t)nqb, nq_pad, D, KS, w.qhat, w.inv_q, w.eq,
+                       reset_flag ? overflow_out : nullptr, qblocks, meta, inv_norm, use16 ? rho : nullptr, N, now,
+                       e_fix, e_cos, w.rowc);
     if ((rc = check_launch())) return rc;
     CoarseArgs c{};
-    c.bank = bank; c.rowc = w.rowc; c.qhat = w.qhat; c.inv_q = w.inv_q;
-    // the shadow is only usable when its rows are 16-byte aligned
-    c.bank16 = (bank16 && (D & 7) == 0 && (reinterpret_cast<uintptr_t>(bank16) & 15) == 0) ? bank16 : nullptr;
+    c.bank = bank; c.rowc = w.rowc; c.qhat = w.qhat; c.inv_q = w.inv_q; c.eq = w.eq;
+    c.bank16 = use16 ? bank16 : nullptr;
     static const int cs_dbg = getenv("AURA_CS_DBG") ? atoi(getenv("AURA_CS_DBG")) : 0;
     c.dbg = cs_dbg;
     c.N = N; c.D = D; c.nq = nqb;
@@ -1762,6 +1727,7 @@ inline int run_coarse_pass(const float* bank, const uint16_t* bank16, const floa
     RefineArgs r{};
     r.bank = bank; r.inv_norm = inv_norm; r.meta = meta; r.queries = qptr; r.inv_q = w.inv_q;
     r.now = now; r.e_cos = e_cos; r.N = N; r.D = D; r.k = k; r.cnt = w.cnt;
+    r.rho = use16 ? rho : nullptr; r.eq = w.eq; r.e_fix = e_fix; r.eq_worst = coarse_eq_worst((float)D);
     r.cand_scores = w.cand_scores; r.cand_idx = w.cand_idx; r.cap = w.cap; r.idx_base = idx_base;
     r.out_scores = out_scores; r.out_idx = out_idx; r.overflow = overflow_out;
     static int rtm_left = 3;                                 // AURA_CS_DBG bit 128: refine phase times
@@ -1829,13 +1795,13 @@ int aura_bank_decay(float* meta, float rate, int64_t count, void* stream) {
     return check_launch();
 }
 
-int aura_bank_gather(const float* bank, const int32_t* idx, float* out, int64_t n, int64_t D,
+int aura_bank_gather(const float* bank, int64_t rows, const int32_t* idx, float* out, int64_t n, int64_t D,
                      void* stream) {
-    if (n < 0 || D <= 0) return AURA_E_INVAL;
+    if (n < 0 || D <= 0 || rows < 0) return AURA_E_INVAL;
     if (n == 0) return AURA_OK;
     if (!bank || !idx || !out) return AURA_E_INVAL;
     hipLaunchKernelGGL(bank_gather_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), bank, idx, out, n, D);
+                       static_cast<hipStream_t>(stream), bank, idx, out, n, D, rows);
     return check_launch();
 }
 
@@ -1844,7 +1810,7 @@ int64_t aura_knn_workspace_bytes(int64_t N, int64_t nq, int k) {
     return carve(nullptr, N, nq, k).bytes;
 }
 
-static int knn_search_impl(const float* bank, const uint16_t* bank_bf16, const float* inv_norm,
+static int knn_search_impl(const float* bank, const uint16_t* bank_bf16, const float* rho, const float* inv_norm,
                            const float* meta, const float* loc,
                            int spatial_dims, const float* queries, const float* q_loc, float now,
                            int64_t N, int64_t D, int64_t nq, int k, int32_t idx_base, float* out_scores,
@@ -1884,7 +1850,7 @@ static int knn_search_impl(const float* bank, const uint16_t* bank_bf16, const f
                     return rc;
                 pmask = w.probe;
             }
-            if ((rc = run_coarse_pass(bank, bank_bf16, inv_norm, meta, qptr, now, N, D, nqb, k, idx_base,
+            if ((rc = run_coarse_pass(bank, bank_bf16, rho, inv_norm, meta, qptr, now, N, D, nqb, k, idx_base,
                                       out_scores + qb0 * k, out_idx + qb0 * k, w, overflow_out,
                                       qb0 == 0, pmask, s)))
                 return rc;
@@ -2024,17 +1990,18 @@ int aura_knn_search_ex(const float* bank, const float* inv_norm, const float* me
                        int64_t N, int64_t D, int64_t nq, int k, int32_t idx_base, float* out_scores,
                        int32_t* out_idx, void* workspace, int64_t workspace_bytes, int flags,
                        int32_t* overflow_out, const float* centroids, int nprobe, void* stream) {
-    return knn_search_impl(bank, nullptr, inv_norm, meta, loc, spatial_dims, queries, q_loc, now, N, D, nq,
+    return knn_search_impl(bank, nullptr, nullptr, inv_norm, meta, loc, spatial_dims, queries, q_loc, now, N, D, nq,
                            k, idx_base, out_scores, out_idx, workspace, workspace_bytes, flags,
                            overflow_out, centroids, nprobe, stream);
 }
 
-int aura_knn_search_shadow(const float* bank, const uint16_t* bank_bf16, const float* inv_norm,
+int aura_knn_search_shadow(const float* bank, const uint16_t* bank_bf16, const float* rho, const float* inv_norm,
                            const float* meta, const float* queries, float now, int64_t N, int64_t D,
                            int64_t nq, int k, int32_t idx_base, float* out_scores, int32_t* out_idx,
                            void* workspace, int64_t workspace_bytes, int flags, int32_t* overflow_out,
                            const float* centroids, int nprobe, void* stream) {
-    return knn_search_impl(bank, bank_bf16, inv_norm, meta, nullptr, 0, queries, nullptr, now, N, D, nq, k,
+    if (bank_bf16 && !rho) return AURA_E_INVAL;
+    return knn_search_impl(bank, bank_bf16, rho, inv_norm, meta, nullptr, 0, queries, nullptr, now, N, D, nq, k,
                            idx_base, out_scores, out_idx, workspace, workspace_bytes, flags, overflow_out,
                            centroids, nprobe, stream);
 }
@@ -2044,21 +2011,8 @@ int64_t aura_knn_ivf2_workspace_bytes(int64_t n_sorted, int64_t nq, int k) {
     return carve_ivf2(nullptr, n_sorted, nq, k).bytes;
 }
 
-int aura_bank_shadow_sorted(const float* bank, const int32_t* sorted_rows, uint16_t* sorted_bf16,
-                            int64_t n_sorted, int64_t D, void* stream) {
-    if (n_sorted < 0 || D <= 0 || (D & 7)) return AURA_E_INVAL;
-    if (n_sorted == 0) return AURA_OK;
-    if (!bank || !sorted_rows || !sorted_bf16) return AURA_E_INVAL;
-    if ((reinterpret_cast<uintptr_t>(bank) & 15) || (reinterpret_cast<uintptr_t>(sorted_bf16) & 15)) return AURA_E_ALIGN;
-    int64_t blocks = (n_sorted * (D / 8) + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(bank_shadow_sorted_kernel, dim3((unsigned)blocks), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), bank, sorted_rows, sorted_bf16, n_sorted, D);
-    return check_launch();
-}
-
 int aura_knn_search_ivf2(const float* bank, const float* inv_norm, const float* meta,
-                         const uint16_t* sorted_bf16, const int32_t* sorted_rows, const int32_t* pad_off,
+                         const uint16_t* sorted_bf16, const float* rho, const int32_t* sorted_rows, const int32_t* pad_off,
                          const int32_t* list_len, int64_t n_sorted, int64_t N, const float* queries, float now,
                          int64_t D, int64_t nq, int k,
                          const float* centroids, int nprobe, int32_t idx_base, float* out_scores,
@@ -2069,7 +2023,7 @@ int aura_knn_search_ivf2(const float* bank, const float* inv_norm, const float* 
         return AURA_E_INVAL;
     if (nprobe <= 0 || nprobe > 8) return AURA_E_INVAL;
     if (nq == 0) return AURA_OK;
-    if (!bank || !inv_norm || !meta || !sorted_bf16 || !sorted_rows || !pad_off || !list_len || !queries || !centroids ||
+    if (!bank || !inv_norm || !meta || !sorted_bf16 || !rho || !sorted_rows || !pad_off || !list_len || !queries || !centroids ||
         !out_scores || !out_idx || !workspace)
         return AURA_E_INVAL;
     if ((reinterpret_cast<uintptr_t>(meta) & 15) || (reinterpret_cast<uintptr_t>(sorted_bf16) & 15) ||
@@ -2081,7 +2035,7 @@ int aura_knn_search_ivf2(const float* bank, const float* inv_norm, const float* 
     if (w.bytes > workspace_bytes) return AURA_E_INVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int KS = D <= 256 ? 8 : (D <= 512 ? 16 : 24);
-    const float e_cos = 0.00390625f * (1.0f + 0.001953125f) + 2.0f * (float)D * 5.9604645e-8f + 1e-5f;
+    const float e_fix = 2.0f * (float)D * 5.9604645e-8f + 1e-5f;   // see aura_knn_coarse.inl
     const int cus = device_cu_count();
     int rc;
     // AURA_IVF2_TRACE: synchronise after every stage and name it on stderr (to localise a device fault)
@@ -2104,20 +2058,21 @@ int aura_knn_search_ivf2(const float* bank, const float* inv_norm, const float* 
                            w.work_counter, 0x7fffffff, 32, nullptr);
         if ((rc = check_launch())) return rc;
         stage("prepare");
-        hipLaunchKernelGGL(ivf2_plan_kernel, dim3(1), dim3(256), 0, s, w.lq_cnt, pad_off, w.blk_off,
+        hipLaunchKernelGGL(ivf2_plan_kernel, dim3(1), dim3(256), 0, s, w.lq_cnt, pad_off, list_len, w.blk_off,
                            w.blk_list, w.blk_row0, w.blk_stride, w.item_off, w.sitem_off, w.nblk);
         if ((rc = check_launch())) return rc;
         stage("plan");
         const int qblocks = IVF2_MAXBLK * 256 / 4;
         hipLaunchKernelGGL(ivf2_prep_kernel, dim3((unsigned)(qblocks + (n_sorted + 255) / 256)), dim3(256), 0, s,
                            qptr, (int64_t)nqb, D, KS, w.lq_cnt, w.lq_list, w.blk_off, w.blk_list, w.nblk, w.qhat,
-                           w.inv_q, w.slotq, w.qslot, w.thr, qb0 == 0 ? overflow_out : nullptr, qblocks, meta,
-                           inv_norm, sorted_rows, n_sorted, now, e_cos, w.rowc);
+                           w.inv_q, w.slotq, w.qslot, w.thr, qb0 == 0 ? overflow_out : nullptr, w.eq_slot, w.eq_q,
+                           qblocks, meta, rho, sorted_rows, n_sorted, now, e_fix, w.rowc);
         if ((rc = check_launch())) return rc;
         stage("prep");
 
         CoarseArgs c{};
         c.bank = bank; c.bank16 = sorted_bf16; c.rowc = w.rowc; c.qhat = w.qhat; c.inv_q = w.inv_q;
+        c.eq = w.eq_slot;
         c.N = n_sorted; c.D = D; c.nq = IVF2_MAXBLK * 256;
         c.thr = w.thr; c.cnt = w.cnt; c.cand_scores = w.cand_scores; c.cand_idx = w.cand_idx; c.cap = w.cap;
         c.blk_row0 = w.blk_row0; c.blk_stride = w.blk_stride; c.nblk = w.nblk; c.slotq = w.slotq;
@@ -2138,7 +2093,7 @@ int aura_knn_search_ivf2(const float* bank, const float* inv_norm, const float* 
         if ((rc = launch(CS_MODE_SAMPLE))) return rc;
         stage("sample scan");
         hipLaunchKernelGGL(ivf2_threshold_kernel, dim3((unsigned)((nqb + 3) / 4)), dim3(256), 0, s, w.gmax,
-                           w.qslot, w.blk_list, pad_off, nprobe, k, nqb, w.thr, w.cnt);
+                           w.qslot, w.blk_list, list_len, nprobe, k, nqb, w.thr, w.cnt);
         if ((rc = check_launch())) return rc;
         stage("threshold");
         c.gmax = nullptr; c.item_off = w.item_off;
@@ -2154,7 +2109,8 @@ int aura_knn_search_ivf2(const float* bank, const float* inv_norm, const float* 
 
         RefineArgs r{};
         r.bank = bank; r.inv_norm = inv_norm; r.meta = meta; r.queries = qptr; r.inv_q = w.inv_q;
-        r.now = now; r.e_cos = e_cos; r.N = N; r.D = D; r.k = k; r.cnt = w.cnt;
+        r.now = now; r.e_cos = 0.0f; r.N = N; r.D = D; r.k = k; r.cnt = w.cnt;
+        r.rho = rho; r.eq = w.eq_q; r.e_fix = e_fix; r.eq_worst = coarse_eq_worst((float)D);
         r.cand_scores = w.cand_scores; r.cand_idx = w.cand_idx; r.cap = w.cap; r.idx_base = idx_base;
         r.out_scores = out_scores + qb0 * k; r.out_idx = out_idx + qb0 * k; r.overflow = overflow_out;
         if (trace) {                                         // candidate lists with row ids outside the bank
@@ -2183,20 +2139,6 @@ int aura_knn_search_ivf2(const float* bank, const float* inv_norm, const float* 
         stage("refine");
     }
     return AURA_OK;
-}
-
-int aura_bank_shadow_update(const float* bank, uint16_t* bank_bf16, const int64_t* slots, int64_t row0,
-                            int64_t n, int64_t D, void* stream) {
-    if (n < 0 || D <= 0 || (D & 7) || row0 < 0) return AURA_E_INVAL;
-    if (n == 0) return AURA_OK;
-    if (!bank || !bank_bf16) return AURA_E_INVAL;
-    if ((reinterpret_cast<uintptr_t>(bank) & 15) || (reinterpret_cast<uintptr_t>(bank_bf16) & 15)) return AURA_E_ALIGN;
-    const int64_t work = n * (D / 8);
-    int64_t blocks = (work + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(bank_shadow_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       bank, bank_bf16, slots, row0, n, D);
-    return check_launch();
 }
 
 int aura_knn_search(const float* bank, const float* inv_norm, const float* meta, const float* loc,
@@ -2380,25 +2322,6 @@ int aura_kmeans_assign(const float* bank, const float* centroids, float* cnorm2_
     a.row_begin = 0; a.row_end = N; a.tile_step = 1;
     a.qnorm2 = cnorm2_ws; a.assign_out = assign_out;
     return launch_scan<8, 1, 4>(a, MODE_ASSIGN, (N + 127) / 128, s);
-}
-
-int aura_kmeans_update(const float* bank, const int32_t* assign, float* centroids, float* counts,
-                       float* meta, int64_t N, int64_t D, int k, int update_means, void* stream) {
-    if (N < 0 || D <= 0 || k <= 0 || k > 256) return AURA_E_INVAL;
-    if (!bank || !assign || !centroids) return AURA_E_INVAL;
-    const size_t lds = (size_t)4 * D * sizeof(float);
-    if (lds > 150 * 1024) return AURA_E_INVAL;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kmeans_update_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
-            return AURA_E_LAUNCH;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(kmeans_update_kernel, dim3((unsigned)k), dim3(256), lds,
-                       static_cast<hipStream_t>(stream), bank, assign, centroids, counts, meta, N, D,
-                       update_means);
-    return check_launch();
 }
 
 int aura_profile_begin(int max_launches) {

@@ -4,11 +4,23 @@
 // Why: the fp32 matrix pipe (v_mfma_f32_32x32x2_f32, 1/16 of the bf16 rate) bounds the exact scan
 // at ~0.35 ms for 256 queries x 100 k rows.  A scan in bf16 is bound by reading the bank once from
 // HBM instead.  Results stay those of the fp32 path because the bf16 score is only used as a
-// bound:
-//     |cos_bf16 - cos_fp32| <= E_cos  with  E_cos = 2^-8 (1 + 2^-9) + 2 D 2^-24 + 1e-5
-// (round-to-nearest bf16 of both operands, Cauchy-Schwarz on the normalised vectors, fp32
-// accumulation of D terms in either pipe), so with  E_row = 0.5 E_cos |strength_row|
-//     L = coarse - E_row  <=  exact score  <=  coarse + E_row = U.
+// bound.  With q_hat, r_hat the normalised query / row and b_q = bf16(q_hat), b_r = bf16(r_hat):
+//     b_q.b_r - q_hat.r_hat = q_hat.e_r + e_q.r_hat + e_q.e_r,   e_x = b_x - x_hat
+//     |cos_bf16 - cos_fp32| <= rho_r + rho_q + rho_r rho_q + E_fix,   rho_x >= ||e_x||_2
+// (Cauchy-Schwarz on unit vectors; E_fix = 2 D 2^-24 + 1e-5 covers the fp32 accumulation of D
+// terms in either pipe and the association of the score formulas).  Round-to-nearest bf16 has
+// unit roundoff 2^-8, so the worst case is rho = 2^-8 each: E_worst = 2^-7 (1 + 2^-9) + E_fix.
+//   * bf16-row kernels (SRC16): the shadow holds the NORMALISED rows and aura_bank.hip records
+//     every row's actual rho_r beside it (typically 0.0017 at D = 768); rho_q is measured per
+//     query by the prep kernel -> a rigorous bound about half the worst case.  eq = rho_q (1 + 2^-7)
+//     >= rho_q (1 + rho_r) enters the scan as the accumulators' initial value (+eq for U, -eq for
+//     L), the row's part (rho_r + E_fix) through its constants:
+//         U = A (t + eq) + B_up,  L = A (t - eq) + B_lo,  A = 0.5 strength,
+//         B = 0.2 exp(-(now - ts)/3600) strength +- 0.5 |strength| (rho_r + E_fix)
+//     (rows with a negative strength get 2 |A| eq_worst on top: A (t + eq) then under-states U).
+//   * fp32-row kernels (no shadow): rows are rounded on the fly, nothing is known about their
+//     residual: E_worst for every pair (A = 0.5 strength / ||row||, accumulators start at 0).
+// So  L <= exact score <= U  for every (query, row) pair:
 //   1. coarse_scan<SAMPLE>: group maxima of L over a strided sample of 16-row groups;
 //      sample_threshold_kernel: T = k-th largest group maximum  (k distinct rows score >= T);
 //   2. coarse_scan<FILTER> over every row: rows with U >= T go to the query's candidate list;
@@ -63,6 +75,7 @@ struct CoarseArgs {
     const float4* rowc;      // [N] per-row score constants {A, B_up, B_lo, centroid id} (coarse_prep_kernel)
     const uint16_t* qhat;    // bf16 query fragments, [nq/256][4 waves][4 blocks][KS][64 lanes][8]
     const float* inv_q;      // [nq]
+    const float* eq;         // [nq] (IVF: [block slot]) query part of the error bound; SRC16 kernels only
     int64_t N, D;
     int nq;
     int64_t n_tiles;         // 16-row tiles this launch walks (per 256-query block)
@@ -257,32 +270,59 @@ __device__ __forceinline__ void mfma_bf16_q(f32x4v& acc, const bf16x8v& af, cons
     }
 }
 
+// Query part of the error bound from the rounding residual e2 = sum (bf16(x) - x)^2 of the normalised
+// query: eq = rho_q (1 + 2^-7), rho_q = 1.001 sqrt(e2) + (D/2 + 3) 2^-24 (see aura_bank.hip for the
+// second term).  EQ_WORST bounds it for any query (round-to-nearest: ||e_q|| <= 2^-8 ||q_hat||).
+__device__ __forceinline__ float coarse_eq_from_e2(float e2, float D) {
+    return (1.001f * sqrtf(e2) + (0.5f * D + 3.0f) * 5.9604645e-8f) * 1.0078125f;
+}
+__host__ __device__ __forceinline__ float coarse_eq_worst(float D) {
+    return (1.001f * 0.00390625f * 1.00001f + (0.5f * D + 3.0f) * 5.9604645e-8f) * 1.0078125f;
+}
+
+// Per-row score constants {A, B_up, B_lo, w} of the two-stage path (w: centroid id / bank row id).
+//   rho != NULL (normalised bf16 shadow rows): A = 0.5 strength, the row's error part from rho[row];
+//   rho == NULL (fp32 rows rounded on the fly): A = 0.5 strength / ||row||, worst-case error e_worst.
+__device__ __forceinline__ float4 coarse_row_constants(const float4 m, float inv_norm_row, const float* rho_row,
+                                                       float now, float e_fix, float e_worst, float eq_worst,
+                                                       float w) {
+    const float strength = m.x;
+    const float tw = 0.2f * expf(-(now - m.y) / 3600.0f);
+    float A, err;
+    if (rho_row) {
+        A = 0.5f * strength;
+        err = 0.5f * fabsf(strength) * (*rho_row + e_fix);
+        if (strength < 0.0f) err += fabsf(strength) * eq_worst;     // 2 |A| eq_worst
+    } else {
+        A = 0.5f * inv_norm_row * strength;
+        err = 0.5f * e_worst * fabsf(strength);
+    }
+    return make_float4(A, tw * strength + err, tw * strength - err, w);
+}
+
 // Per-call preparation for the two-stage path, one launch:
-//   blocks [0, qblocks): 4 queries each (one wave per query): 1/||q|| (as query_prep_kernel) and the
+//   blocks [0, qblocks): 4 queries each (one wave per query): 1/||q|| (as query_prep_kernel), the
 //     query as bf16 MFMA B-fragments in the order coarse_scan_kernel's waves load them
-//     ([256-query block][wave][16-query block][k-step][lane][8], zero padded): a fragment is one
-//     coalesced 1-KiB wave load;
-//   blocks [qblocks, ...): 256 rows each: the row's share of the combined score folded into
-//     U = t * A + B_up,  L = t * A + B_lo   with t = (q / ||q||) . row:
-//     A = 0.5 strength / ||row||,  B = 0.2 exp(-(now - ts)/3600) strength +- E_row.
-//     (Association differs from the exact epilogue by a few ulp: covered by the 1e-5 in E_cos.)
+//     ([256-query block][wave][16-query block][k-step][lane][8], zero padded: a fragment is one
+//     coalesced 1-KiB wave load) and eq[q], the query's part of the error bound;
+//   blocks [qblocks, ...): 256 rows each: the row's share of the combined score (see the header).
+//     (Association differs from the exact epilogue by a few ulp: covered by the 1e-5 in E_fix.)
 __global__ __launch_bounds__(256) void coarse_prep_kernel(const float* __restrict__ x, int64_t nq,
                                                           int64_t nq_pad, int64_t D, int KS,
                                                           uint16_t* __restrict__ qhat,
-                                                          float* __restrict__ inv, int32_t* overflow,
+                                                          float* __restrict__ inv, float* __restrict__ eq_out,
+                                                          int32_t* overflow,
                                                           int qblocks, const float* __restrict__ meta,
                                                           const float* __restrict__ inv_norm,
-                                                          int64_t N, float now, float e_cos,
+                                                          const float* __restrict__ rho,
+                                                          int64_t N, float now, float e_fix, float e_worst,
                                                           float4* __restrict__ rowc) {
     if ((int)blockIdx.x >= qblocks) {
         const int64_t row = ((int64_t)blockIdx.x - qblocks) * 256 + threadIdx.x;
         if (row >= N) return;
         const float4 m = *reinterpret_cast<const float4*>(meta + row * 4);
-        const float strength = m.x;
-        const float tw = 0.2f * expf(-(now - m.y) / 3600.0f);
-        const float err = 0.5f * e_cos * fabsf(strength);
-        const float A = 0.5f * inv_norm[row] * strength;
-        rowc[row] = make_float4(A, tw * strength + err, tw * strength - err, m.z);   // .w: centroid id
+        rowc[row] = coarse_row_constants(m, inv_norm[row], rho ? rho + row : nullptr, now, e_fix, e_worst,
+                                         coarse_eq_worst((float)D), m.z);   // .w: centroid id
         return;
     }
     const int lane = threadIdx.x & 63;
@@ -304,6 +344,7 @@ __global__ __launch_bounds__(256) void coarse_prep_kernel(const float* __restric
     const float iqv = 1.0f / fmaxf(sqrtf(s), 1e-12f);
     if (lane == 0 && q < nq) inv[q] = iqv;
     // fragments hold the NORMALISED query: the scan's accumulator is the cosine numerator / ||q||
+    float e2 = 0.0f;
     for (int c = lane; c < KS * 4; c += 64) {             // chunk c: k = 8c .. 8c+7 = k-step c/4, lg c%4
         f32x8v v;
 #pragma unroll
@@ -317,9 +358,15 @@ __global__ __launch_bounds__(256) void coarse_prep_kernel(const float* __restric
                 v[4] = w.x * iqv; v[5] = w.y * iqv; v[6] = w.z * iqv; v[7] = w.w * iqv;
             }
         }
-        *reinterpret_cast<bf16x8v*>(base + ((int64_t)(c >> 2) * 64 + (c & 3) * 16) * 8) =
-            __builtin_convertvector(v, bf16x8v);
+        const bf16x8v bv = __builtin_convertvector(v, bf16x8v);
+        *reinterpret_cast<bf16x8v*>(base + ((int64_t)(c >> 2) * 64 + (c & 3) * 16) * 8) = bv;
+        const f32x8v back = __builtin_convertvector(bv, f32x8v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = back[e] - v[e]; e2 = fmaf(d, d, e2); }
     }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) e2 += __shfl_xor(e2, off);
+    if (lane == 0 && eq_out) eq_out[q] = q < nq ? coarse_eq_from_e2(e2, (float)D) : 0.0f;
 }
 
 // T[q] = k-th largest of the G group maxima: one wave per query, PER keys per lane in registers;
@@ -466,6 +513,10 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
     const uint32_t buf_addr = cs_base + NSLOT * SLOT_BYTES;
     const uint32_t wreg_addr = buf_addr + wave * (2 * WCAP * 12);
     const uint32_t mask_addr = buf_addr + CS_BUF * 12;            // [256][8] probe masks (MASKED) / [256] slot -> query (IVF)
+    // [256] query parts of the error bound (SRC16), signed for the mode: kept in LDS, not in registers --
+    // two more live VGPRs across the tile loop made the 24-k-step 8-wave kernels spill inside it
+    constexpr int EQ_OFF = CS_BUF * 12 + (MASKED ? 256 * 32 : (IVF ? 256 * 4 : 0));
+    const uint32_t eq_addr = buf_addr + EQ_OFF;
     int wc[2] = {0, 0};                                    // fill counts of this wave's halves (wave-uniform)
     // span-end write-out of both halves: every slot reservation is issued before any is waited for
     // (up to 4 entries per lane), then one wait, then the stores
@@ -535,6 +586,16 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
             }
             __syncthreads();
         }
+        // query part of the error bound: the accumulators start at +eq (FILTER: U) / -eq (SAMPLE: L)
+        if (SRC16) {
+            float* const s_eq = reinterpret_cast<float*>(csmem + NSLOT * SLOT_BYTES + EQ_OFF);
+            if (tid < 256) {
+                const int64_t q = qblk * 256 + tid;
+                const float v = a.eq[q < a.nq ? q : a.nq - 1];
+                s_eq[tid] = MODE == CS_MODE_FILTER ? v : -v;
+            }
+            __syncthreads();
+        }
         if (MODE == CS_MODE_FILTER) {                       // thresholds first: their wait must not
             uint32_t key[QB];                              // sit between the fragment loads
 #pragma unroll
@@ -593,6 +654,16 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
             asm volatile("" ::: "memory");
             const uint32_t ts1 = stamp();
             const int par = (int)(t & 1);
+            // this wave's eq values: read here, consumed by the accumulator set-up behind the DMA issue
+            uint32_t eqr[QB];
+            if (SRC16) {
+                uint32_t ln2 = (uint32_t)lane;
+                asm volatile("" : "+v"(ln2));                // recomputed per tile (see issue())
+                const uint32_t ea = eq_addr + (uint32_t)(wave * (16 * QB)) * 4u + (ln2 & 15u) * 4u;
+#pragma unroll
+                for (int b = 0; b < QB; ++b)
+                    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(eqr[b]) : "v"(ea), "n"(64 * b) : "memory");
+            }
             // The half tile t-1 appended to is stable during this tile.  Once it holds enough entries
             // it is written out in two steps that never stall the stream: the slot reservations
             // (returning atomics) are issued here, ahead of the next tile's LDS-DMA, and consumed after
@@ -613,10 +684,15 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
             if (t + 2 < seg && !(a.dbg & 4)) issue(j0 + t + 2, (slot + 2) % NSLOT);
 
             auto mma = [&]() {
+            if (SRC16) {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(eqr[0])::"memory");
+#pragma unroll
+                for (int b = 1; b < QB; ++b) asm volatile("" : "+v"(eqr[b])::"memory");
+            }
 #pragma unroll
             for (int b = 0; b < QB; ++b)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[b][e] = 0.0f;
+                for (int e = 0; e < 4; ++e) acc[b][e] = SRC16 ? __uint_as_float(eqr[b]) : 0.0f;
             // fragment reads run two k-steps ahead of the MFMAs (one wave per SIMD: nothing else
             // hides the LDS latency)
             constexpr int PF = (SRC16 && NW == 4) ? CS_PF16 : 2;   // k-steps the reads run ahead (8 waves: registers are short, the other wave hides the latency)
@@ -851,7 +927,10 @@ struct RefineArgs {
     const float* meta;
     const float* queries;
     const float* inv_q;
-    float now, e_cos;
+    float now, e_cos;           // e_cos: worst-case bound, used when rho == NULL (fp32-row prefilter)
+    const float* rho;           // [N] per-row error norms of the bf16 shadow (NULL: no shadow)
+    const float* eq;            // [nq] query parts of the bound (with rho)
+    float e_fix, eq_worst;
     int64_t N, D;
     int k;
     const int32_t* cnt;
@@ -892,6 +971,7 @@ __global__ __launch_bounds__(RF_THREADS) void coarse_refine_kernel(const RefineA
     int ovf_bits = 0;
     if (n > capn) { ovf = true; ovf_bits |= 4; n = capn; }
 
+    const float eqq = a.rho ? a.eq[q] : 0.0f;
     for (int i = tid; i < n; i += RF_THREADS) {
         float u = a.cand_scores[(int64_t)q * a.cap + i];
         int32_t r = a.cand_idx[(int64_t)q * a.cap + i];
@@ -899,7 +979,11 @@ __global__ __launch_bounds__(RF_THREADS) void coarse_refine_kernel(const RefineA
             if (a.overflow) atomicOr(a.overflow, 16);
             r = 0; u = -INFINITY;
         }
-        const float err = 0.5f * a.e_cos * fabsf(a.meta[(int64_t)r * 4]);
+        // the pair's error as the scan kernels formed it (see the header): L = U - 2 err
+        const float strength = a.meta[(int64_t)r * 4];
+        float err = 0.5f * a.e_cos * fabsf(strength);
+        if (a.rho)
+            err = 0.5f * fabsf(strength) * (a.rho[r] + a.e_fix + (strength < 0.0f ? 2.0f * a.eq_worst : eqq));
         s_u[i] = u;
         s_i[i] = r;
         s_l[i] = ord_key(u - 2.0f * err);
@@ -1075,16 +1159,10 @@ inline bool coarse_eligible(const float* bank, const uint16_t* bank16, const flo
 template <int KS, bool SRC16, bool MASKED, int NW = 4>
 inline int launch_coarse(const CoarseArgs& a, int mode, int grid, hipStream_t s) {
     const size_t lds = (size_t)CS_SLOTS * (KS * (SRC16 ? 1024 : 2048) + CS_AUX_BYTES) + (size_t)CS_BUF * 12 +
-                       (MASKED ? 256 * 32 : 0);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(coarse_scan_kernel<KS, CS_MODE_SAMPLE, SRC16, MASKED, false, NW>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(coarse_scan_kernel<KS, CS_MODE_FILTER, SRC16, MASKED, false, NW>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return AURA_E_LAUNCH;
-        attr_set = true;
-    }
+                       (MASKED ? 256 * 32 : 0) + (SRC16 ? 256 * 4 : 0);
+    if (ensure_lds_attr(reinterpret_cast<const void*>(coarse_scan_kernel<KS, CS_MODE_SAMPLE, SRC16, MASKED, false, NW>), (int)lds) ||
+        ensure_lds_attr(reinterpret_cast<const void*>(coarse_scan_kernel<KS, CS_MODE_FILTER, SRC16, MASKED, false, NW>), (int)lds))
+        return AURA_E_LAUNCH;
     if (mode == CS_MODE_SAMPLE)
         hipLaunchKernelGGL((coarse_scan_kernel<KS, CS_MODE_SAMPLE, SRC16, MASKED, false, NW>), dim3(grid), dim3(64 * NW), lds, s, a);
     else
@@ -1120,21 +1198,4 @@ inline int dispatch_coarse(const CoarseArgs& a, int mode, int grid, hipStream_t 
     if (ks <= 8) return launch_coarse<8, false, false>(a, mode, grid, s);
     if (ks <= 16) return launch_coarse<16, false, false>(a, mode, grid, s);
     return launch_coarse<24, false, false>(a, mode, grid, s);
-}
-
-// bf16 shadow rows: shadow[r] = bf16(bank[r]) for r in slots[0..n) or [row0, row0 + n)
-__global__ __launch_bounds__(256) void bank_shadow_kernel(const float* __restrict__ bank,
-                                                          uint16_t* __restrict__ shadow,
-                                                          const int64_t* __restrict__ slots, int64_t row0,
-                                                          int64_t n, int64_t D) {
-    const int64_t per = D / 8;                               // 16-byte output chunks per row
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n * per; i += (int64_t)gridDim.x * 256) {
-        const int64_t r = i / per, c = i - r * per;
-        const int64_t row = slots ? slots[r] : row0 + r;
-        const float4 u = *reinterpret_cast<const float4*>(bank + row * D + 8 * c);
-        const float4 w = *reinterpret_cast<const float4*>(bank + row * D + 8 * c + 4);
-        f32x8v x;
-        x[0] = u.x; x[1] = u.y; x[2] = u.z; x[3] = u.w; x[4] = w.x; x[5] = w.y; x[6] = w.z; x[7] = w.w;
-        *reinterpret_cast<bf16x8v*>(shadow + row * D + 8 * c) = __builtin_convertvector(x, bf16x8v);
-    }
 }

@@ -25,7 +25,8 @@ constexpr int IVF2_MAXBLK = 256 + IVF_MAXQ * 8 / 256;   // blocks of one pass at
 
 // ---- plan: blocks, their row ranges and the work-item prefixes (one workgroup) ----
 __global__ __launch_bounds__(256) void ivf2_plan_kernel(const int32_t* __restrict__ lq_cnt,
-                                                        const int32_t* __restrict__ pad_off,   // [257] padded row offsets
+                                                        const int32_t* __restrict__ pad_off,   // [257] first sorted row of each list
+                                                        const int32_t* __restrict__ list_len,  // [256] entries in use (holes included)
                                                         int32_t* blk_off,    // [257] first block of each list
                                                         int32_t* blk_list,   // [MAXBLK] list of block B
                                                         int32_t* blk_row0,   // [MAXBLK]
@@ -38,29 +39,41 @@ __global__ __launch_bounds__(256) void ivf2_plan_kernel(const int32_t* __restric
     s_nb[tid + 1] = (lq_cnt[tid] + 255) / 256;
     if (tid == 0) s_nb[0] = 0;
     __syncthreads();
-    if (tid == 0)
-        for (int c = 1; c <= 256; ++c) s_nb[c] += s_nb[c - 1];
-    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {              // inclusive scan of s_nb[1..256]
+        const int add = tid >= off ? s_nb[tid + 1 - off] : 0;
+        __syncthreads();
+        s_nb[tid + 1] += add;
+        __syncthreads();
+    }
     blk_off[tid] = s_nb[tid];
     if (tid == 0) { blk_off[256] = s_nb[256]; nblk[0] = s_nb[256]; }
-    const int tiles = (pad_off[tid + 1] - pad_off[tid]) / 16;
+    const int tiles = (list_len[tid] + 15) / 16;
     for (int b = s_nb[tid]; b < s_nb[tid + 1]; ++b) {
         blk_list[b] = tid;
         blk_row0[b] = pad_off[tid];
         blk_stride[b] = tiles > IVF2_STILES ? tiles / IVF2_STILES : 1;   // sample tiles j * stride, j < 32
     }
     __syncthreads();
-    if (tid == 0) {                                       // <= 320 blocks: a serial prefix is fine
-        int it = 0, st = 0;
-        for (int c = 0; c < 256; ++c) {
-            const int tl = (pad_off[c + 1] - pad_off[c]) / 16;
-            for (int b = s_nb[c]; b < s_nb[c + 1]; ++b) {
-                item_off[b] = it; sitem_off[b] = st;
-                it += tl; st += tl < IVF2_STILES ? tl : IVF2_STILES;
-            }
-        }
-        item_off[s_nb[256]] = it; sitem_off[s_nb[256]] = st;
+    // work-item prefixes: list c contributes (blocks of c) x (tiles of c) filter items and
+    // (blocks of c) x min(tiles, STILES) sample items; exclusive scan over the lists in LDS
+    __shared__ int s_it[257], s_st[257];
+    const int nb = s_nb[tid + 1] - s_nb[tid];
+    const int stl = tiles < IVF2_STILES ? tiles : IVF2_STILES;
+    s_it[tid + 1] = nb * tiles; s_st[tid + 1] = nb * stl;
+    if (tid == 0) { s_it[0] = 0; s_st[0] = 0; }
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const int a_it = tid >= off ? s_it[tid + 1 - off] : 0;
+        const int a_st = tid >= off ? s_st[tid + 1 - off] : 0;
+        __syncthreads();
+        s_it[tid + 1] += a_it; s_st[tid + 1] += a_st;
+        __syncthreads();
     }
+    for (int b = s_nb[tid], j = 0; b < s_nb[tid + 1]; ++b, ++j) {
+        item_off[b] = s_it[tid] + j * tiles;
+        sitem_off[b] = s_st[tid] + j * stl;
+    }
+    if (tid == 0) { item_off[s_nb[256]] = s_it[256]; sitem_off[s_nb[256]] = s_st[256]; }
 }
 
 // ---- prep: per block slot the query's bf16 fragments, the slot <-> query maps, +inf thresholds;
@@ -74,10 +87,11 @@ __global__ __launch_bounds__(256) void ivf2_prep_kernel(const float* __restrict_
                                                         uint16_t* __restrict__ qhat, float* __restrict__ inv,
                                                         int32_t* __restrict__ slotq, int32_t* __restrict__ qslot,
                                                         uint32_t* __restrict__ thr, int32_t* overflow,
+                                                        float* __restrict__ eq_slot, float* __restrict__ eq_q,
                                                         int qblocks, const float* __restrict__ meta,
-                                                        const float* __restrict__ inv_norm,
+                                                        const float* __restrict__ rho,
                                                         const int32_t* __restrict__ sorted_rows, int64_t Npad,
-                                                        float now, float e_cos, float4* __restrict__ rowc) {
+                                                        float now, float e_fix, float4* __restrict__ rowc) {
     if ((int)blockIdx.x >= qblocks) {
         const int64_t i = ((int64_t)blockIdx.x - qblocks) * 256 + threadIdx.x;
         if (i >= Npad) return;
@@ -87,11 +101,8 @@ __global__ __launch_bounds__(256) void ivf2_prep_kernel(const float* __restrict_
             return;
         }
         const float4 m = *reinterpret_cast<const float4*>(meta + (int64_t)row * 4);
-        const float strength = m.x;
-        const float tw = 0.2f * expf(-(now - m.y) / 3600.0f);
-        const float err = 0.5f * e_cos * fabsf(strength);
-        const float A = 0.5f * inv_norm[row] * strength;
-        rowc[i] = make_float4(A, tw * strength + err, tw * strength - err, __int_as_float(row));
+        rowc[i] = coarse_row_constants(m, 0.0f, rho + row, now, e_fix, 0.0f, coarse_eq_worst((float)D),
+                                       __int_as_float(row));
         return;
     }
     const int lane = threadIdx.x & 63;
@@ -124,6 +135,7 @@ __global__ __launch_bounds__(256) void ivf2_prep_kernel(const float* __restrict_
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
     const float iqv = 1.0f / fmaxf(sqrtf(s), 1e-12f);
     if (lane == 0 && used) inv[q] = iqv;                   // (written by each of the query's 8 slots: same value)
+    float e2 = 0.0f;
     for (int c = lane; c < KS * 4; c += 64) {
         f32x8v v;
 #pragma unroll
@@ -137,8 +149,18 @@ __global__ __launch_bounds__(256) void ivf2_prep_kernel(const float* __restrict_
                 v[4] = w.x * iqv; v[5] = w.y * iqv; v[6] = w.z * iqv; v[7] = w.w * iqv;
             }
         }
-        *reinterpret_cast<bf16x8v*>(base + ((int64_t)(c >> 2) * 64 + (c & 3) * 16) * 8) =
-            __builtin_convertvector(v, bf16x8v);
+        const bf16x8v bv = __builtin_convertvector(v, bf16x8v);
+        *reinterpret_cast<bf16x8v*>(base + ((int64_t)(c >> 2) * 64 + (c & 3) * 16) * 8) = bv;
+        const f32x8v back = __builtin_convertvector(bv, f32x8v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = back[e] - v[e]; e2 = fmaf(d, d, e2); }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) e2 += __shfl_xor(e2, off);
+    if (lane == 0) {                                        // query part of the error bound (coarse_prep_kernel)
+        const float eqv = used ? coarse_eq_from_e2(e2, (float)D) : 0.0f;
+        eq_slot[vs] = eqv;
+        if (used) eq_q[q] = eqv;                            // (each of the query's slots: same value)
     }
 }
 
@@ -146,7 +168,7 @@ __global__ __launch_bounds__(256) void ivf2_prep_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void ivf2_threshold_kernel(const float* __restrict__ gmax,       // [slots][2 STILES]
                                                              const int32_t* __restrict__ qslot,    // [nq][8]
                                                              const int32_t* __restrict__ blk_list,
-                                                             const int32_t* __restrict__ pad_off,
+                                                             const int32_t* __restrict__ list_len,
                                                              int nprobe, int k, int nq,
                                                              uint32_t* __restrict__ thr,
                                                              int32_t* __restrict__ cnt_out) {
@@ -160,7 +182,7 @@ __global__ __launch_bounds__(256) void ivf2_threshold_kernel(const float* __rest
     if (p < nprobe) {
         vs = qslot[(int64_t)q * 8 + p];
         const int list = blk_list[vs >> 8];
-        const int tiles = (pad_off[list + 1] - pad_off[list]) / 16;
+        const int tiles = (list_len[list] + 15) / 16;
         const int groups = 2 * (tiles < IVF2_STILES ? tiles : IVF2_STILES);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -185,27 +207,6 @@ __global__ __launch_bounds__(256) void ivf2_threshold_kernel(const float* __rest
     if (lane == 0) cnt_out[(int64_t)q * CNT_STRIDE] = 0;
 }
 
-// sorted_shadow[i] = bf16(bank[sorted_rows[i]]) (zeros for pads)
-__global__ __launch_bounds__(256) void bank_shadow_sorted_kernel(const float* __restrict__ bank,
-                                                                 const int32_t* __restrict__ sorted_rows,
-                                                                 uint16_t* __restrict__ out, int64_t Npad,
-                                                                 int64_t D) {
-    const int64_t per = D / 8;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < Npad * per; i += (int64_t)gridDim.x * 256) {
-        const int64_t r = i / per, c = i - r * per;
-        const int32_t row = sorted_rows[r];
-        f32x8v x;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] = 0.0f;
-        if (row >= 0) {
-            const float4 u = *reinterpret_cast<const float4*>(bank + (int64_t)row * D + 8 * c);
-            const float4 w = *reinterpret_cast<const float4*>(bank + (int64_t)row * D + 8 * c + 4);
-            x[0] = u.x; x[1] = u.y; x[2] = u.z; x[3] = u.w; x[4] = w.x; x[5] = w.y; x[6] = w.z; x[7] = w.w;
-        }
-        *reinterpret_cast<bf16x8v*>(out + r * D + 8 * c) = __builtin_convertvector(x, bf16x8v);
-    }
-}
-
 struct Ivf2Workspace {
     // shared with the lists / coarse paths
     float* inv_q; uint32_t* probe; float* probe_dist; int32_t* probe_ids;
@@ -214,6 +215,7 @@ struct Ivf2Workspace {
     // two-stage inverted lists
     int32_t* blk_off; int32_t* blk_list; int32_t* blk_row0; int32_t* blk_stride; int32_t* item_off; int32_t* sitem_off; int32_t* nblk;
     int32_t* slotq; int32_t* qslot; uint32_t* thr; float* gmax; uint16_t* qhat; float4* rowc;
+    float* eq_slot; float* eq_q;
     int cap; int qp; int64_t bytes;
 };
 
@@ -251,6 +253,8 @@ static Ivf2Workspace carve_ivf2(void* base, int64_t Npad, int64_t nq, int k) {
     w.slotq = reinterpret_cast<int32_t*>(take((int64_t)IVF2_MAXBLK * 256 * 4));
     w.qslot = reinterpret_cast<int32_t*>(take(qp * 8 * 4));
     w.thr = reinterpret_cast<uint32_t*>(take((int64_t)IVF2_MAXBLK * 256 * 4));
+    w.eq_slot = reinterpret_cast<float*>(take((int64_t)IVF2_MAXBLK * 256 * 4));
+    w.eq_q = reinterpret_cast<float*>(take(qp * 4));
     w.gmax = reinterpret_cast<float*>(take((int64_t)IVF2_MAXBLK * 256 * 2 * IVF2_STILES * 4));
     w.qhat = reinterpret_cast<uint16_t*>(take((int64_t)IVF2_MAXBLK * 256 * 768 * 2));
     w.rowc = reinterpret_cast<float4*>(take((Npad > 0 ? Npad : 1) * 16));
@@ -260,16 +264,10 @@ static Ivf2Workspace carve_ivf2(void* base, int64_t Npad, int64_t nq, int k) {
 
 template <int KS, int NW>
 inline int launch_coarse_ivf(const CoarseArgs& a, int mode, int grid, hipStream_t s) {
-    const size_t lds = (size_t)CS_SLOTS * (KS * 1024 + CS_AUX_BYTES) + (size_t)CS_BUF * 12 + 256 * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(coarse_scan_kernel<KS, CS_MODE_SAMPLE, true, false, true, NW>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(coarse_scan_kernel<KS, CS_MODE_FILTER, true, false, true, NW>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return AURA_E_LAUNCH;
-        attr_set = true;
-    }
+    const size_t lds = (size_t)CS_SLOTS * (KS * 1024 + CS_AUX_BYTES) + (size_t)CS_BUF * 12 + 256 * 4 + 256 * 4;
+    if (ensure_lds_attr(reinterpret_cast<const void*>(coarse_scan_kernel<KS, CS_MODE_SAMPLE, true, false, true, NW>), (int)lds) ||
+        ensure_lds_attr(reinterpret_cast<const void*>(coarse_scan_kernel<KS, CS_MODE_FILTER, true, false, true, NW>), (int)lds))
+        return AURA_E_LAUNCH;
     if (mode == CS_MODE_SAMPLE)
         hipLaunchKernelGGL((coarse_scan_kernel<KS, CS_MODE_SAMPLE, true, false, true, NW>), dim3(grid), dim3(64 * NW), lds, s, a);
     else

@@ -210,12 +210,14 @@ def bank_row_norms(bank, inv_norm, row0: int, n: int) -> None:
           "aura_bank_row_norms")
 
 
-def bank_shadow_update(bank, shadow, row0: int = 0, n: Optional[int] = None, slots=None) -> None:
-    """shadow[r] = bf16(bank[r]) for the rows ``slots`` (int64 [n], device) or [row0, row0 + n)."""
+def bank_shadow_update(bank, inv_norm, shadow, rho, row0: int = 0, n: Optional[int] = None, slots=None) -> None:
+    """shadow[r] = bf16(bank[r] * inv_norm[r]) (the normalised row) and rho[r] = its L2 rounding
+    residual, for the rows ``slots`` (int64 [n], device) or [row0, row0 + n)."""
     _need(bank, "bank", torch.float32); _need(shadow, "shadow", torch.bfloat16)
+    _need(inv_norm, "inv_norm", torch.float32); _need(rho, "rho", torch.float32)
     M, D = bank.shape
-    if shadow.shape != bank.shape or D % 8:
-        raise ValueError("bank_shadow_update: shadow must match the bank and D % 8 == 0")
+    if shadow.shape != bank.shape or D % 8 or inv_norm.numel() != M or rho.numel() != M:
+        raise ValueError("bank_shadow_update: shadow must match the bank, D % 8 == 0, inv_norm / rho [rows]")
     if slots is not None:
         _need(slots, "slots", torch.int64)
         n = slots.numel()
@@ -223,8 +225,17 @@ def bank_shadow_update(bank, shadow, row0: int = 0, n: Optional[int] = None, slo
         n = M - row0
     if row0 < 0 or n < 0 or (slots is None and row0 + n > M):
         raise ValueError("bank_shadow_update: range out of bounds")
-    check(lib().aura_bank_shadow_update(_p(bank), _p(shadow), _p(slots), row0, n, D, _stream()),
-          "aura_bank_shadow_update")
+    check(lib().aura_bank_shadow_update(_p(bank), _p(inv_norm), _p(shadow), _p(rho), _p(slots), row0, n, D,
+                                        _stream()), "aura_bank_shadow_update")
+
+
+def make_shadow(bank, inv_norm, count: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(shadow bf16 [M, D], rho fp32 [M]) of rows [0, count) of a bank whose 1/||row|| are current."""
+    M, D = bank.shape
+    shadow = torch.empty(M, D, dtype=torch.bfloat16, device=bank.device)
+    rho = torch.zeros(M, dtype=torch.float32, device=bank.device)
+    bank_shadow_update(bank, inv_norm, shadow, rho, 0, M if count is None else count)
+    return shadow, rho
 
 
 def bank_write(bank, loc, meta, inv_norm, feats, slots, cur_loc, now: float,
@@ -259,28 +270,47 @@ def bank_decay(meta, rate: float, count: int) -> None:
     check(lib().aura_bank_decay(_p(meta), rate, count, _stream()), "aura_bank_decay")
 
 
+# Scratch memory and the overflow flag are per (device, stream): two recalls in flight on different
+# HIP streams never share candidate lists, thresholds or flags.  A buffer that has to grow is replaced
+# (the old one is returned to torch's caching allocator, which keeps it alive for work already queued
+# on its stream).
 _workspaces = {}
 _ovf_flags = {}
 
 
+def _wkey(device):
+    return (device, torch.cuda.current_stream(device).cuda_stream)
+
+
 def _workspace(device, nbytes: int) -> torch.Tensor:
-    ws = _workspaces.get(device)
+    key = _wkey(device)
+    ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
-        _workspaces[device] = ws
+        _workspaces[key] = ws
     return ws
+
+
+def _overflow_flag(device) -> torch.Tensor:
+    """int32 [1], reset by the library's prep kernel on every call."""
+    key = _wkey(device)
+    f = _ovf_flags.get(key)
+    if f is None:
+        f = _ovf_flags[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return f
 
 
 def knn_search(bank, inv_norm, meta, queries, k: int, now: float, count: Optional[int] = None,
                loc=None, q_loc=None, idx_base: int = 0, force_dense: bool = False,
                centroids=None, nprobe: int = 0, check_overflow: bool = True,
-               fp32_scan: bool = False, shadow=None) -> Tuple[torch.Tensor, torch.Tensor]:
+               fp32_scan: bool = False, shadow=None, rho=None, return_flag: bool = False):
     """Exact batched recall over rows [0, count) -> (scores [nq, k] fp32, idx [nq, k] int32).
 
     ``centroids`` (256 x D) + ``nprobe`` switches on the reference's centroid-candidate
     selection.  ``check_overflow`` reads one int back (a host sync) and transparently re-runs the
     dense path if a candidate list overflowed; pass False inside latency-critical loops whose
-    data is known to be well behaved.
+    data is known to be well behaved.  ``return_flag`` additionally returns the overflow flag
+    (int32 [1] on the device) so that a caller can fold the check into a read of its own.
     """
     _need(bank, "bank", torch.float32); _need(inv_norm, "inv_norm", torch.float32)
     _need(meta, "meta", torch.float32); _need(queries, "queries", torch.float32)
@@ -307,26 +337,24 @@ def knn_search(bank, inv_norm, meta, queries, k: int, now: float, count: Optiona
     out_s = torch.empty(nq, k, dtype=torch.float32, device=dev)
     out_i = torch.empty(nq, k, dtype=torch.int32, device=dev)
     if nq == 0:
-        return out_s, out_i
+        return (out_s, out_i, torch.zeros(1, dtype=torch.int32, device=dev)) if return_flag else (out_s, out_i)
     L = lib()
     nbytes = L.aura_knn_workspace_bytes(N, nq, k)
     if nbytes < 0:
         raise _lib.AuraHipError("aura_knn_workspace_bytes failed")
     ws = _workspace(dev, nbytes)
     base = (ws.data_ptr() + 255) // 256 * 256
-    ovf = _ovf_flags.get(dev)          # reset by the library's prep kernel on every call
-    if ovf is None:
-        ovf = _ovf_flags[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
+    ovf = _overflow_flag(dev)
 
     use_shadow = shadow is not None and q_loc is None
     if use_shadow:
-        _need(shadow, "shadow", torch.bfloat16)
-        if shadow.shape != bank.shape:
-            raise ValueError("knn_search: shadow must have the bank's shape")
+        _need(shadow, "shadow", torch.bfloat16); _need(rho, "rho", torch.float32)
+        if shadow.shape != bank.shape or rho.numel() != M:
+            raise ValueError("knn_search: shadow must have the bank's shape, rho one entry per row")
 
     def run(flags):
         if use_shadow:
-            check(L.aura_knn_search_shadow(_p(bank), _p(shadow), _p(inv_norm), _p(meta), _p(queries), now,
+            check(L.aura_knn_search_shadow(_p(bank), _p(shadow), _p(rho), _p(inv_norm), _p(meta), _p(queries), now,
                                            N, D, nq, k, idx_base, _p(out_s), _p(out_i), base, nbytes,
                                            flags, _p(ovf), _p(centroids), nprobe, _stream()),
                   "aura_knn_search_shadow")
@@ -339,7 +367,7 @@ def knn_search(bank, inv_norm, meta, queries, k: int, now: float, count: Optiona
     run(_lib.KNN_FORCE_DENSE if force_dense else (_lib.KNN_FP32_SCAN if fp32_scan else 0))
     if check_overflow and not force_dense and int(ovf.item()) != 0:
         run(_lib.KNN_FORCE_DENSE)
-    return out_s, out_i
+    return (out_s, out_i, ovf) if return_flag else (out_s, out_i)
 
 
 def ivf_capacity(longest_lists_total: int, k: int) -> Optional[int]:
@@ -373,9 +401,7 @@ def knn_search_ivf(bank, inv_norm, meta, queries, k: int, now: float, count: int
     dev = bank.device
     out_s = torch.empty(nq, k, dtype=torch.float32, device=dev)
     out_i = torch.empty(nq, k, dtype=torch.int32, device=dev)
-    ovf = torch.zeros(1, dtype=torch.int32, device=dev) if nq == 0 else _ovf_flags.get(dev)
-    if ovf is None:
-        ovf = _ovf_flags[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
+    ovf = torch.zeros(1, dtype=torch.int32, device=dev) if nq == 0 else _overflow_flag(dev)
     if nq == 0:
         return out_s, out_i, ovf
     L = lib()
@@ -391,75 +417,139 @@ def knn_search_ivf(bank, inv_norm, meta, queries, k: int, now: float, count: int
     return out_s, out_i, ovf
 
 
-def ivf2_layout(list_rows, list_off, list_len):
-    """Padded, list-sorted layout for knn_search_ivf2 from the inverted lists of knn_search_ivf:
-    returns (sorted_rows int32 [n_sorted] with -1 pads, pad_off int32 [257]); every list starts at a
-    multiple of 16."""
-    dev = list_rows.device
-    lens = list_len.to(torch.int64)
-    pad_len = (lens + 15) // 16 * 16
-    pad_off = torch.zeros(257, dtype=torch.int64, device=dev)
-    pad_off[1:] = torch.cumsum(pad_len, 0)
-    n_sorted = max(16, int(pad_off[256].item()))
-    sorted_rows = torch.full((n_sorted,), -1, dtype=torch.int32, device=dev)
-    off = list_off.to(torch.int64)
-    total = int(lens.sum().item())
-    if total:
-        lid = torch.repeat_interleave(torch.arange(256, device=dev), lens)          # list of each listed row
-        src = torch.arange(total, device=dev) + off[0]                               # position in list_rows
-        dst = pad_off[lid] + (src - off[lid])
-        sorted_rows[dst] = list_rows[src]
-    return sorted_rows.contiguous(), pad_off.to(torch.int32).contiguous()
+def ivf2_slack(update_interval: int) -> int:
+    """Free entries kept behind every inverted list (a multiple of 16): writes between two centroid
+    rebuilds (every ``update_interval`` inserts in the reference) are appended in place."""
+    return (min(max(int(update_interval), 64), 512) + 15) // 16 * 16
 
 
-def bank_shadow_sorted(bank, sorted_rows) -> torch.Tensor:
-    """bf16 rows in ``sorted_rows`` order (zeros where it is -1)."""
+def ivf2_alloc_rows(max_rows: int, slack: int) -> int:
+    """Sorted rows to allocate for a bank of ``max_rows``: every list padded to 16 plus its slack."""
+    return (int(max_rows) + 256 * (slack + 16) + 15) // 16 * 16
+
+
+def ivf2_layout(order, seg_off, slack: int, sorted_rows, pad_off, list_len) -> None:
+    """Fill the list-sorted layout (in place, no host sync) from rows grouped by centroid id:
+    ``order`` int32 [n] (rows of list c = order[seg_off[c] : seg_off[c+1]]), ``seg_off`` int32 [257].
+    ``sorted_rows`` int32 [n_alloc] <- row ids, -1 elsewhere; ``pad_off`` int32 [257] <- list starts
+    (multiples of 16, ``slack`` free entries behind every list); ``list_len`` int32 [256]."""
+    dev = order.device
+    off = seg_off.to(torch.int64)
+    lens = off[1:] - off[:-1]
+    cap = (lens + slack + 15) // 16 * 16
+    po = torch.zeros(257, dtype=torch.int64, device=dev)
+    po[1:] = torch.cumsum(cap, 0)
+    pad_off.copy_(po.to(torch.int32))
+    list_len.copy_(lens.to(torch.int32))
+    sorted_rows.fill_(-1)
+    n = order.numel()                                          # rows before seg_off[0] have no list
+    if n:
+        pos = torch.arange(n, device=dev, dtype=torch.int64)
+        lid = torch.searchsorted(off[1:].contiguous(), pos, right=True).clamp_(max=255)
+        dst = po[lid] + (pos - off[lid])
+        listed = pos >= off[0]
+        sorted_rows[dst[listed]] = order[listed]
+
+
+def bank_shadow_sorted(bank, inv_norm, sorted_rows, out, rho, pos_of_row=None, n_sorted: Optional[int] = None) -> None:
+    """out[i] = bf16 shadow row of bank row sorted_rows[i] (zeros where it is -1) for i < n_sorted;
+    refreshes rho[row] and the reverse map pos_of_row[row] = i."""
     _need(bank, "bank", torch.float32); _need(sorted_rows, "sorted_rows", torch.int32)
-    D = bank.shape[1]
-    if D % 8:
-        raise ValueError("bank_shadow_sorted: D % 8 == 0 required")
-    out = torch.empty(sorted_rows.numel(), D, dtype=torch.bfloat16, device=bank.device)
-    check(lib().aura_bank_shadow_sorted(_p(bank), _p(sorted_rows), _p(out), sorted_rows.numel(), D, _stream()),
-          "aura_bank_shadow_sorted")
-    return out
+    _need(inv_norm, "inv_norm", torch.float32); _need(rho, "rho", torch.float32)
+    _need(out, "out", torch.bfloat16)
+    M, D = bank.shape
+    n = sorted_rows.numel() if n_sorted is None else int(n_sorted)
+    if D % 8 or out.shape[1] != D or not (0 <= n <= min(sorted_rows.numel(), out.shape[0])) or \
+            inv_norm.numel() != M or rho.numel() != M:
+        raise ValueError("bank_shadow_sorted: shape mismatch")
+    if pos_of_row is not None:
+        _need(pos_of_row, "pos_of_row", torch.int32)
+        if pos_of_row.numel() != M:
+            raise ValueError("bank_shadow_sorted: pos_of_row must have one entry per bank row")
+    check(lib().aura_bank_shadow_sorted(_p(bank), _p(inv_norm), _p(sorted_rows), _p(out), _p(rho), _p(pos_of_row),
+                                        n, D, _stream()), "aura_bank_shadow_sorted")
+
+
+def build_ivf2(bank, inv_norm, cids, slack: int = 0, max_rows: Optional[int] = None, rho=None):
+    """Inverted lists in the layout of ``knn_search_ivf2`` for rows [0, n) with centroid ids ``cids``
+    (any numeric dtype, < 0: no list): returns a dict with sorted_bf16, rho, sorted_rows, pad_off,
+    list_len, pos_of_row, flag, n_sorted (sorted rows in use)."""
+    dev = bank.device
+    M, D = bank.shape
+    n = cids.numel()
+    order, seg_off = group_by_cluster(cids, 256)
+    n_alloc = ivf2_alloc_rows(M if max_rows is None else max_rows, slack)
+    st = dict(sorted_bf16=torch.empty(n_alloc, D, dtype=torch.bfloat16, device=dev),
+              sorted_rows=torch.empty(n_alloc, dtype=torch.int32, device=dev),
+              pad_off=torch.zeros(257, dtype=torch.int32, device=dev),
+              list_len=torch.zeros(256, dtype=torch.int32, device=dev),
+              pos_of_row=torch.full((M,), -1, dtype=torch.int32, device=dev),
+              flag=torch.zeros(1, dtype=torch.int32, device=dev),
+              rho=torch.zeros(M, dtype=torch.float32, device=dev) if rho is None else rho,
+              n_sorted=min(n_alloc, ivf2_alloc_rows(n, slack)), slack=slack)
+    ivf2_layout(order, seg_off, slack, st["sorted_rows"], st["pad_off"], st["list_len"])
+    bank_shadow_sorted(bank, inv_norm, st["sorted_rows"], st["sorted_bf16"], st["rho"], st["pos_of_row"],
+                       st["n_sorted"])
+    return st
+
+
+def ivf2_append(bank, inv_norm, meta, slots, sorted_shadow, sorted_rows, pad_off, list_len, pos_of_row, rho,
+                flag) -> None:
+    """Keep the inverted lists current after a write of the DISTINCT rows ``slots`` (int64 [n]): the
+    row's old entry becomes a hole, the row is appended to the list of meta[slot][2]."""
+    _need(bank, "bank", torch.float32); _need(inv_norm, "inv_norm", torch.float32)
+    _need(meta, "meta", torch.float32); _need(slots, "slots", torch.int64)
+    _need(sorted_shadow, "sorted_shadow", torch.bfloat16); _need(rho, "rho", torch.float32)
+    for t, n_ in ((sorted_rows, "sorted_rows"), (pad_off, "pad_off"), (list_len, "list_len"),
+                  (pos_of_row, "pos_of_row"), (flag, "flag")):
+        _need(t, n_, torch.int32)
+    M, D = bank.shape
+    if sorted_shadow.shape[1] != D or sorted_shadow.shape[0] < sorted_rows.numel() or pad_off.numel() != 257 or \
+            list_len.numel() != 256 or pos_of_row.numel() != M or rho.numel() != M or meta.shape != (M, 4) or D % 8:
+        raise ValueError("ivf2_append: shape mismatch")
+    check(lib().aura_ivf2_append(_p(bank), _p(inv_norm), _p(meta), _p(slots), slots.numel(), D, _p(sorted_shadow),
+                                 _p(sorted_rows), _p(pad_off), _p(list_len), _p(pos_of_row), _p(rho), _p(flag),
+                                 _stream()), "aura_ivf2_append")
 
 
 def knn_search_ivf2(bank, inv_norm, meta, queries, k: int, now: float, centroids, nprobe: int,
-                    sorted_shadow, sorted_rows, pad_off, list_len, idx_base: int = 0
+                    sorted_shadow, rho, sorted_rows, pad_off, list_len, idx_base: int = 0,
+                    n_sorted: Optional[int] = None
                     ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """Inverted-list recall through the two-stage scan: (scores [nq, k], idx [nq, k], overflow flag [1]).
-    Same results as ``knn_search_ivf``; ``sorted_*`` / ``pad_off`` from ``ivf2_layout`` +
-    ``bank_shadow_sorted``."""
+    Same results as ``knn_search_ivf``; layout arrays from ``ivf2_layout`` + ``bank_shadow_sorted``
+    (kept current by ``ivf2_append``).  ``n_sorted``: sorted rows in use (a multiple of 16 that covers
+    pad_off[256]; default: all of ``sorted_rows``)."""
     _need(bank, "bank", torch.float32); _need(inv_norm, "inv_norm", torch.float32)
     _need(meta, "meta", torch.float32); _need(queries, "queries", torch.float32)
     _need(centroids, "centroids", torch.float32); _need(sorted_shadow, "sorted_shadow", torch.bfloat16)
+    _need(rho, "rho", torch.float32)
     for t, n in ((sorted_rows, "sorted_rows"), (pad_off, "pad_off"), (list_len, "list_len")):
         _need(t, n, torch.int32)
     M, D = bank.shape
     nq = queries.shape[0]
-    n_sorted = sorted_rows.numel()
-    if queries.dim() != 2 or queries.shape[1] != D or meta.shape != (M, 4):
+    ns = sorted_rows.numel() if n_sorted is None else int(n_sorted)
+    if queries.dim() != 2 or queries.shape[1] != D or meta.shape != (M, 4) or rho.numel() != M:
         raise ValueError("knn_search_ivf2: shape mismatch")
     if centroids.shape != (256, D) or not (0 < nprobe <= 8):
         raise ValueError("knn_search_ivf2: centroids must be [256, D], nprobe in [1, 8]")
-    if sorted_shadow.shape != (n_sorted, D) or pad_off.numel() != 257 or list_len.numel() != 256 or n_sorted % 16:
+    if sorted_shadow.shape[1] != D or not (0 < ns <= min(sorted_rows.numel(), sorted_shadow.shape[0])) or \
+            pad_off.numel() != 257 or list_len.numel() != 256 or ns % 16:
         raise ValueError("knn_search_ivf2: layout arrays do not match")
     if not (0 < k <= 256) or D % 8 or D > 768:
         raise ValueError("knn_search_ivf2: k <= 256, D % 8 == 0, D <= 768")
     dev = bank.device
     out_s = torch.empty(nq, k, dtype=torch.float32, device=dev)
     out_i = torch.empty(nq, k, dtype=torch.int32, device=dev)
-    ovf = torch.zeros(1, dtype=torch.int32, device=dev) if nq == 0 else _ovf_flags.get(dev)
-    if ovf is None:
-        ovf = _ovf_flags[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
+    ovf = torch.zeros(1, dtype=torch.int32, device=dev) if nq == 0 else _overflow_flag(dev)
     if nq == 0:
         return out_s, out_i, ovf
     L = lib()
-    nbytes = L.aura_knn_ivf2_workspace_bytes(n_sorted, nq, k)
+    nbytes = L.aura_knn_ivf2_workspace_bytes(ns, nq, k)
     ws = _workspace(dev, nbytes)
     base = (ws.data_ptr() + 255) // 256 * 256
-    check(L.aura_knn_search_ivf2(_p(bank), _p(inv_norm), _p(meta), _p(sorted_shadow), _p(sorted_rows),
-                                 _p(pad_off), _p(list_len), n_sorted, M, _p(queries), now, D, nq, k,
+    check(L.aura_knn_search_ivf2(_p(bank), _p(inv_norm), _p(meta), _p(sorted_shadow), _p(rho), _p(sorted_rows),
+                                 _p(pad_off), _p(list_len), ns, M, _p(queries), now, D, nq, k,
                                  _p(centroids), nprobe, idx_base, _p(out_s), _p(out_i), base, nbytes,
                                  _p(ovf), _stream()), "aura_knn_search_ivf2")
     return out_s, out_i, ovf
@@ -479,14 +569,12 @@ def topk_merge(scores, idx, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
 
 
 def bank_gather(bank, idx) -> torch.Tensor:
-    """rows of ``bank`` at int32 ``idx`` (any shape); -1 -> zeros."""
+    """rows of ``bank`` at int32 ``idx`` (any shape); indices outside the bank (-1) -> zeros."""
     _need(bank, "bank", torch.float32); _need(idx, "idx", torch.int32)
     D = bank.shape[1]
     n = idx.numel()
-    if n and int(idx.max()) >= bank.shape[0]:
-        raise ValueError("bank_gather: index out of range")
     out = torch.empty(*idx.shape, D, dtype=torch.float32, device=bank.device)
-    check(lib().aura_bank_gather(_p(bank), _p(idx), _p(out), n, D, _stream()), "aura_bank_gather")
+    check(lib().aura_bank_gather(_p(bank), bank.shape[0], _p(idx), _p(out), n, D, _stream()), "aura_bank_gather")
     return out
 
 
@@ -503,24 +591,60 @@ def kmeans_assign(bank, centroids, count: int, k: int) -> torch.Tensor:
     return assign
 
 
-def kmeans_update(bank, assign, centroids, k: int, counts=None, meta=None,
-                  update_means: bool = True) -> None:
-    _need(bank, "bank", torch.float32); _need(assign, "assign", torch.int32)
-    _need(centroids, "centroids", torch.float32)
+def group_by_cluster(assign, k: int = 256) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Rows grouped by cluster id (stable): (order int32 [n], seg_off int32 [k+1]) with
+    order[seg_off[c] : seg_off[c+1]] = rows of cluster c; ids < 0 sort first (seg_off[0] = their
+    count).  Device-side sort + bincount, no host sync."""
+    a = assign.to(torch.int32)
+    order = torch.sort(a, stable=True).indices.to(torch.int32).contiguous()
+    valid = a >= 0
+    lens = torch.bincount(a.clamp(min=0).long(), weights=valid.to(torch.float32), minlength=k)[:k].to(torch.int64)
+    n_neg = (a.numel() - valid.sum()).reshape(1)
+    seg_off = torch.cat([n_neg, n_neg + torch.cumsum(lens, 0)]).to(torch.int32).contiguous()
+    return order, seg_off
+
+
+def kmeans_segment_means(bank, order, seg_off, centroids, k: int) -> None:
+    """centroids[c] = mean of bank[order[seg_off[c]:seg_off[c+1]]] for c < k (empty clusters keep theirs)."""
+    _need(bank, "bank", torch.float32); _need(centroids, "centroids", torch.float32)
+    _need(order, "order", torch.int32); _need(seg_off, "seg_off", torch.int32)
+    M, D = bank.shape
+    N = order.numel()
+    if N > M or centroids.shape[1] != D or not (0 < k <= min(256, centroids.shape[0])) or seg_off.numel() < k + 1 or D % 4:
+        raise ValueError("kmeans_segment_means: shape mismatch")
+    L = lib()
+    nbytes = L.aura_kmeans_means_workspace_bytes(N, D, k)
+    ws = _workspace(bank.device, nbytes)
+    base = (ws.data_ptr() + 255) // 256 * 256
+    check(L.aura_kmeans_segment_means(_p(bank), _p(order), _p(seg_off), _p(centroids), base, nbytes, N, D, k,
+                                      _stream()), "aura_kmeans_segment_means")
+
+
+def kmeans_commit(assign, seg_off, meta, counts, k: int) -> None:
+    """meta[i][2] = assign[i]; counts[c] = rows of cluster c."""
+    _need(assign, "assign", torch.int32); _need(seg_off, "seg_off", torch.int32); _need(meta, "meta", torch.float32)
     N = assign.numel()
-    D = bank.shape[1]
-    if N > bank.shape[0] or centroids.shape[1] != D or not (0 < k <= min(256, centroids.shape[0])):
-        raise ValueError("kmeans_update: shape mismatch")
+    if meta.shape[0] < N or meta.shape[1] != 4 or seg_off.numel() < k + 1 or not (0 < k <= 256):
+        raise ValueError("kmeans_commit: shape mismatch")
     if counts is not None:
         _need(counts, "counts", torch.float32)
         if counts.numel() < k:
-            raise ValueError("kmeans_update: counts too small")
+            raise ValueError("kmeans_commit: counts too small")
+    check(lib().aura_kmeans_commit(_p(assign), _p(seg_off), _p(meta), _p(counts), N, k, _stream()),
+          "aura_kmeans_commit")
+
+
+def kmeans_update(bank, assign, centroids, k: int, counts=None, meta=None, update_means: bool = True):
+    """One Lloyd update from an assignment: means (``update_means``), counts and metadata ids.
+    Returns the grouping (order, seg_off) it used."""
+    order, seg_off = group_by_cluster(assign, k)
+    if update_means:
+        kmeans_segment_means(bank, order, seg_off, centroids, k)
     if meta is not None:
-        _need(meta, "meta", torch.float32)
-        if meta.shape[0] < N or meta.shape[1] != 4:
-            raise ValueError("kmeans_update: meta shape mismatch")
-    check(lib().aura_kmeans_update(_p(bank), _p(assign), _p(centroids), _p(counts), _p(meta), N, D,
-                                   k, 1 if update_means else 0, _stream()), "aura_kmeans_update")
+        kmeans_commit(assign, seg_off, meta, counts, k)
+    elif counts is not None:
+        counts[:k] = (seg_off[1:k + 1] - seg_off[:k]).to(torch.float32)
+    return order, seg_off
 
 
 def addition_linear(x, weight_patterns, bias=None) -> torch.Tensor:

@@ -137,8 +137,10 @@ int aura_knn_search(const float* bank, const float* inv_norm, const float* meta,
 #define AURA_KNN_FORCE_DENSE 1
 /* AURA_KNN_FP32_SCAN: score every row on the fp32 matrix pipe.  Without it, large banks
  * (>= 8192 rows, D <= 768, D % 4 == 0, no location term / centroid mask, k <= 256) are first
- * filtered by a bf16 scan whose error is bounded, and only rows that can still reach the top k are
- * re-scored in fp32 with the same arithmetic: results are bit-identical either way. */
+ * filtered by a bf16 scan whose error is bounded rigorously (round-to-nearest bf16 of both
+ * operands: |cos_bf16 - cos_fp32| <= rho_row + rho_query + rho_row rho_query + 2 D 2^-24 + 1e-5
+ * with rho <= 2^-8 the relative L2 rounding residuals), and only rows that can still reach the top
+ * k are re-scored in fp32 with the same arithmetic: results are bit-identical either way. */
 #define AURA_KNN_FP32_SCAN 2
 int aura_knn_search_ex(const float* bank, const float* inv_norm, const float* meta,
                        const float* loc, int spatial_dims, const float* queries,
@@ -189,56 +191,81 @@ int aura_topk_merge(const float* in_scores, const int32_t* in_idx, int S, int64_
  * assign: assign_out[i] = argmin_c ||bank[i] - centroids[c]|| over the first k centroids
  *   (computed as argmin |c|^2 - 2 x.c on the fp32 matrix cores; ties -> lower c);
  *   cnorm2_ws: k floats of scratch.
- * update: for each c < k, count = #{i: assign[i]==c}; if update_means and count > 0,
- *   centroids[c] = mean of those rows (empty clusters keep their centroid, :362-363);
- *   counts[c] = count (if counts != NULL); meta[i][2] = assign[i] (if meta != NULL). */
+ * segment_means: the masked means of :358-363 as a segmented reduction.  The caller groups the rows
+ *   by cluster (a stable sort of assign): order [N] int32 row ids, seg_off [k+1] int32 with
+ *   order[seg_off[c] .. seg_off[c+1]) = rows of cluster c.  centroids[c] = mean of those rows, summed
+ *   in a fixed order (reproducible); empty clusters keep their centroid (:362-363).  Reads the bank
+ *   once.  D % 4 == 0; workspace: aura_kmeans_means_workspace_bytes(N, D, k) bytes, 16-byte aligned.
+ * commit: meta[i][2] = assign[i] for i < N and counts[c] = seg_off[c+1] - seg_off[c] (counts may be
+ *   NULL) -- the recount / metadata write of :370-376. */
 int aura_kmeans_assign(const float* bank, const float* centroids, float* cnorm2_ws,
                        int32_t* assign_out, int64_t N, int64_t D, int k, void* stream);
-int aura_kmeans_update(const float* bank, const int32_t* assign, float* centroids, float* counts,
-                       float* meta, int64_t N, int64_t D, int k, int update_means, void* stream);
+int64_t aura_kmeans_means_workspace_bytes(int64_t N, int64_t D, int k);
+int aura_kmeans_segment_means(const float* bank, const int32_t* order, const int32_t* seg_off, float* centroids,
+                              void* workspace, int64_t workspace_bytes, int64_t N, int64_t D, int k,
+                              void* stream);
+int aura_kmeans_commit(const int32_t* assign, const int32_t* seg_off, float* meta, float* counts, int64_t N,
+                       int k, void* stream);
 
-/* Gather rows: out[i] = bank[idx[i]] (idx < 0 -> zeros); used to return [B,k,D] memory features
- * (memory_augmented_layer.py:124-128). */
-int aura_bank_gather(const float* bank, const int32_t* idx, float* out, int64_t n, int64_t D,
+/* Gather rows: out[i] = bank[idx[i]] (idx outside [0, rows) -> zeros; rows = rows of the bank); used
+ * to return [B,k,D] memory features (memory_augmented_layer.py:124-128). */
+int aura_bank_gather(const float* bank, int64_t rows, const int32_t* idx, float* out, int64_t n, int64_t D,
                      void* stream);
 
 /* Optional bf16 shadow of the bank for the two-stage recall's prefilter (halves the bytes the
  * prefilter streams; results unchanged: the survivors are still re-scored from the fp32 bank).
  * [build-side] no upstream counterpart; the product keeps it beside memory_features
  * (src/core/hippocampal.py:88) exactly as it keeps 1/||row||.
- * aura_bank_shadow_update: bank_bf16[r] = bf16(bank[r]) for r in slots[0..n) (device int64) or,
- * with slots == NULL, [row0, row0 + n).  D % 8 == 0, both bases 16-byte aligned. */
-int aura_bank_shadow_update(const float* bank, uint16_t* bank_bf16, const int64_t* slots, int64_t row0,
-                            int64_t n, int64_t D, void* stream);
+ * A shadow row is the NORMALISED row rounded to bf16: bank_bf16[r] = bf16(bank[r] * inv_norm[r]);
+ * rho[r] (fp32, [rows of the bank]) is an upper bound of its L2 rounding residual against the unit
+ * row -- the row's part of the prefilter's error bound, measured instead of assumed (<= 2^-8).
+ * aura_bank_shadow_update: rows r in slots[0..n) (device int64) or, with slots == NULL,
+ * [row0, row0 + n); inv_norm must be current for them.  D % 8 == 0, both bases 16-byte aligned. */
+int aura_bank_shadow_update(const float* bank, const float* inv_norm, uint16_t* bank_bf16, float* rho,
+                            const int64_t* slots, int64_t row0, int64_t n, int64_t D, void* stream);
 
-/* aura_knn_search_ex without location term, with the shadow (may be NULL = same as
- * aura_knn_search_ex).  The shadow must hold bf16(bank[r]) for every r < N.  centroids / nprobe as in
- * aura_knn_search_ex: with the shadow the centroid-candidate restriction (hippocampal.py:259-270) is
- * applied inside the two-stage scan (probe masks in LDS) instead of the fp32 scan. */
-int aura_knn_search_shadow(const float* bank, const uint16_t* bank_bf16, const float* inv_norm,
+/* aura_knn_search_ex without location term, with the shadow (bank_bf16 == NULL: same as
+ * aura_knn_search_ex).  bank_bf16 / rho must be current (aura_bank_shadow_update) for every r < N.
+ * centroids / nprobe as in aura_knn_search_ex: with the shadow the centroid-candidate restriction
+ * (hippocampal.py:259-270) is applied inside the two-stage scan (probe masks in LDS) instead of the
+ * fp32 scan. */
+int aura_knn_search_shadow(const float* bank, const uint16_t* bank_bf16, const float* rho, const float* inv_norm,
                            const float* meta, const float* queries, float now, int64_t N, int64_t D,
                            int64_t nq, int k, int32_t idx_base, float* out_scores, int32_t* out_idx,
                            void* workspace, int64_t workspace_bytes, int flags, int32_t* overflow_out,
                            const float* centroids, int nprobe, void* stream);
 
 /* Centroid-index recall (hippocampal.py:259-270) as inverted lists on the two-stage machinery: the
- * caller keeps a LIST-SORTED bf16 shadow -- sorted row i holds bf16(bank[sorted_rows[i]]), rows of one
- * centroid contiguous, every list padded to a multiple of 16 rows (sorted_rows = -1, zeros) -- built
- * with aura_bank_shadow_sorted whenever the lists change.  pad_off [257] = padded list starts
- * (pad_off[256] = n_sorted), list_len [256] = real lengths.  Each probed list is streamed once per
- * batch of up to 2048 queries against the queries that probe it; results (rows, score bits) equal
- * aura_knn_search_ivf's.  N = rows of the bank (every sorted_rows entry is < N).  D % 8 == 0,
- * D <= 768, k <= 256, nprobe <= 8; overflow_out as in
- * aura_knn_search_ex (non-zero: re-run aura_knn_search_ivf or the masked scan). */
+ * caller keeps a LIST-SORTED bf16 shadow -- sorted row i holds the shadow row of bank row
+ * sorted_rows[i] (-1: no row, scanned as padding), the rows of one centroid contiguous.
+ * pad_off [257]: first sorted row of each list, multiples of 16 (pad_off[256] <= n_sorted);
+ * list_len [256]: entries in use, list_len[c] <= pad_off[c+1] - pad_off[c] -- the difference is
+ * slack that aura_ivf2_append fills after writes, so the lists are re-packed only when the centroids
+ * are rebuilt; every entry beyond list_len[c] must be -1.
+ * aura_bank_shadow_sorted converts all n_sorted rows (and refreshes rho[row]; pos_of_row, if not NULL,
+ * receives the reverse map bank row -> sorted row for aura_ivf2_append).
+ * aura_ivf2_append: after a write of n DISTINCT bank rows `slots` (device int64) whose centroid ids
+ * are in meta[.][2]: the row's previous entry becomes a hole (-1), the row is appended to its list
+ * (bf16 row converted, rho refreshed, pos_of_row updated).  The caller guarantees that no list
+ * outgrows its slack (it re-packs after at most `slack` appended rows); *flag |= 1 otherwise.
+ * aura_knn_search_ivf2: each probed list is streamed once per batch of up to 2048 queries against
+ * the queries that probe it; results (rows, score bits) equal aura_knn_search_ivf's.  N = rows of
+ * the bank (every sorted_rows entry is < N).  D % 8 == 0, D <= 768, k <= 256, nprobe <= 8;
+ * overflow_out as in aura_knn_search_ex (non-zero: re-run aura_knn_search_ivf or the masked scan). */
 int64_t aura_knn_ivf2_workspace_bytes(int64_t n_sorted, int64_t nq, int k);
-int aura_bank_shadow_sorted(const float* bank, const int32_t* sorted_rows, uint16_t* sorted_bf16,
-                            int64_t n_sorted, int64_t D, void* stream);
+int aura_bank_shadow_sorted(const float* bank, const float* inv_norm, const int32_t* sorted_rows,
+                            uint16_t* sorted_bf16, float* rho, int32_t* pos_of_row, int64_t n_sorted, int64_t D,
+                            void* stream);
+int aura_ivf2_append(const float* bank, const float* inv_norm, const float* meta, const int64_t* slots,
+                     int64_t n, int64_t D, uint16_t* sorted_bf16, int32_t* sorted_rows, const int32_t* pad_off,
+                     int32_t* list_len, int32_t* pos_of_row, float* rho, int32_t* flag, void* stream);
 int aura_knn_search_ivf2(const float* bank, const float* inv_norm, const float* meta,
-                         const uint16_t* sorted_bf16, const int32_t* sorted_rows, const int32_t* pad_off,
-                         const int32_t* list_len, int64_t n_sorted, int64_t N, const float* queries, float now,
-                         int64_t D, int64_t nq, int k, const float* centroids, int nprobe,
-                         int32_t idx_base, float* out_scores, int32_t* out_idx, void* workspace,
-                         int64_t workspace_bytes, int32_t* overflow_out, void* stream);
+                         const uint16_t* sorted_bf16, const float* rho, const int32_t* sorted_rows,
+                         const int32_t* pad_off, const int32_t* list_len, int64_t n_sorted, int64_t N,
+                         const float* queries, float now, int64_t D, int64_t nq, int k,
+                         const float* centroids, int nprobe, int32_t idx_base, float* out_scores,
+                         int32_t* out_idx, void* workspace, int64_t workspace_bytes, int32_t* overflow_out,
+                         void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Surrogate-gradient training path and the prosody-modulated GIF (fp32, [rows][T][H] layout)

@@ -39,7 +39,8 @@ def bank_decay(meta, rate, count):
 
 
 def knn_search(bank, inv_norm, meta, queries, k, now, count=None, loc=None, q_loc=None, idx_base=0,
-               force_dense=False, centroids=None, nprobe=0, check_overflow=True, fp32_scan=False, shadow=None):
+               force_dense=False, centroids=None, nprobe=0, check_overflow=True, fp32_scan=False, shadow=None,
+               rho=None, return_flag=False):
     N = bank.shape[0] if count is None else count
     nq = queries.shape[0]
     scores = torch.full((nq, k), float("-inf"))
@@ -63,7 +64,7 @@ def knn_search(bank, inv_norm, meta, queries, k, now, count=None, loc=None, q_lo
         if kk:
             s, p = torch.topk(comb, kk)
             scores[i, :kk], idx[i, :kk] = s, (p + idx_base).to(torch.int32)
-    return scores, idx
+    return (scores, idx, torch.zeros(1, dtype=torch.int32)) if return_flag else (scores, idx)
 
 
 def topk_merge(scores, idx, k):
@@ -85,6 +86,15 @@ def kmeans_assign(bank, centroids, count, k):
     return torch.argmin(torch.cdist(bank[:count], centroids[:k]), dim=1).to(torch.int32)
 
 
+def group_by_cluster(assign, k=256):
+    a = assign.to(torch.int32)
+    order = torch.sort(a, stable=True).indices.to(torch.int32)
+    valid = a >= 0
+    lens = torch.bincount(a.clamp(min=0).long(), weights=valid.float(), minlength=k)[:k].long()
+    n_neg = (a.numel() - valid.sum()).reshape(1)
+    return order, torch.cat([n_neg, n_neg + torch.cumsum(lens, 0)]).to(torch.int32)
+
+
 def kmeans_update(bank, assign, centroids, k, counts=None, meta=None, update_means=True):
     n = assign.numel()
     for c in range(k):
@@ -95,6 +105,11 @@ def kmeans_update(bank, assign, centroids, k, counts=None, meta=None, update_mea
             counts[c] = m.sum()
     if meta is not None:
         meta[:n, 2] = assign.float()
+    return group_by_cluster(assign, k)
+
+
+def ivf2_slack(update_interval):
+    return (min(max(int(update_interval), 64), 512) + 15) // 16 * 16
 
 
 def ivf_capacity(longest_lists_total, k):

@@ -1,6 +1,6 @@
 """Randomised agreement sweep: inverted lists on the two-stage scan and the masked two-stage scan vs the
-masked fp32 scan, bit for bit.
-python tools/ivf2_fuzz.py [cases] [seed]"""
+masked fp32 scan, bit for bit (test infrastructure).
+python tests/fuzz_ivf2.py [cases] [seed]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -29,20 +29,15 @@ def sweep(cases=30, seed=0, dev=None, verbose=True):
         meta[:, 2] = ops.kmeans_assign(bank, cent, N, ncent).float()
         if ri(0, 1): meta[::53, 2] = -1.0
         q = (bank[torch.randint(0, N, (nq,), generator=g).to(dev)] + 0.3 * bank.std() * torch.randn(nq, D, generator=g).to(dev)).contiguous()
-        cids = meta[:, 2].to(torch.int32)
-        order = torch.sort(cids, stable=True).indices.to(torch.int32).contiguous()
-        valid = cids >= 0
-        lens = torch.bincount(cids.clamp(min=0).long(), weights=valid.float(), minlength=256)[:256].to(torch.int32).contiguous()
-        n_neg = (N - valid.sum()).to(torch.int32).reshape(1)
-        off = torch.cat([n_neg, n_neg + torch.cumsum(lens, 0).to(torch.int32)]).contiguous()
-        srows, pad_off = ops.ivf2_layout(order, off, lens)
-        sshadow = ops.bank_shadow_sorted(bank, srows)
-        s1, r1, o1 = ops.knn_search_ivf2(bank, inv, meta, q, k, now, cent, 8, sshadow, srows, pad_off, lens)
+        slack = [0, 64][ri(0, 1)]                      # packed lists / lists with free entries behind them
+        st = ops.build_ivf2(bank, inv, meta[:, 2], slack=slack)
+        s1, r1, o1 = ops.knn_search_ivf2(bank, inv, meta, q, k, now, cent, 8, st["sorted_bf16"], st["rho"],
+                                         st["sorted_rows"], st["pad_off"], st["list_len"], n_sorted=st["n_sorted"])
         flag = int(o1.item())
         s0, r0 = ops.knn_search(bank, inv, meta, q, k, now, centroids=cent, nprobe=8, fp32_scan=True)
         # third path: the masked two-stage scan over the (unsorted) bf16 shadow
-        shadow = torch.empty(N, D, dtype=torch.bfloat16, device=dev); ops.bank_shadow_update(bank, shadow)
-        s2, r2 = ops.knn_search(bank, inv, meta, q, k, now, centroids=cent, nprobe=8, shadow=shadow)
+        shadow, rho = ops.make_shadow(bank, inv)
+        s2, r2 = ops.knn_search(bank, inv, meta, q, k, now, centroids=cent, nprobe=8, shadow=shadow, rho=rho)
         masked_ok = bool(torch.equal(r0, r2) and torch.equal(s0, s2))
         del shadow
         if flag:
@@ -56,7 +51,7 @@ def sweep(cases=30, seed=0, dev=None, verbose=True):
         if verbose or not ok:
             print(f"case {c}: N={N} D={D} nq={nq} k={k} ncent={ncent}: {'ok' if ok else 'MISMATCH'} {note}", flush=True)
         bad += 0 if ok else 1
-        del bank, sshadow
+        del bank, st
     return bad
 
 

@@ -1,5 +1,6 @@
 """Randomised agreement sweep: two-stage recall (fp32 rows and bf16 shadow) vs the all-fp32 scan,
-bit for bit, over random shapes / data / metadata.  python tools/two_stage_fuzz.py [cases] [seed]"""
+bit for bit, over random shapes / data / metadata (test infrastructure).
+python tests/fuzz_two_stage.py [cases] [seed]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -39,13 +40,13 @@ def sweep(cases=40, seed=0, dev=None, verbose=True):
         s0, i0 = ops.knn_search(bank, inv, meta, q, k, now, fp32_scan=True)
         s1, i1 = ops.knn_search(bank, inv, meta, q, k, now)
         ok = torch.equal(i0, i1) and torch.equal(s0, s1)
-        ovf = int(ops._ovf_flags[dev].item())
+        ovf = int(ops._overflow_flag(dev).item())
         txt = f"case {c}: N={N} D={D} nq={nq} k={k} kind={kind} meta={mk}: fp32-rows {'ok' if ok else 'MISMATCH'} (fallback={ovf})"
         if D % 8 == 0:
-            sh = torch.empty(N, D, dtype=torch.bfloat16, device=dev); ops.bank_shadow_update(bank, sh)
-            s2, i2 = ops.knn_search(bank, inv, meta, q, k, now, shadow=sh)
+            sh, rho = ops.make_shadow(bank, inv)
+            s2, i2 = ops.knn_search(bank, inv, meta, q, k, now, shadow=sh, rho=rho)
             ok2 = torch.equal(i0, i2) and torch.equal(s0, s2)
-            txt += f" | shadow {'ok' if ok2 else 'MISMATCH'} (fallback={int(ops._ovf_flags[dev].item())})"
+            txt += f" | shadow {'ok' if ok2 else 'MISMATCH'} (fallback={int(ops._overflow_flag(dev).item())})"
             ok = ok and ok2
             del sh
         if verbose or not ok:

@@ -249,8 +249,10 @@ def test_rebuild_centroids_vs_oracle(dev):
     agree = (a == b).float().mean().item()
     assert agree >= 0.995, f"assignment agreement {agree}"
     assert torch.allclose(hf.centroid_counts.cpu().sum(), torch.tensor(5000.0))
-    big = ob.centroid_counts > 5
-    assert torch.allclose(hf.centroids.cpu()[big], ob.centroids[big], rtol=1e-3, atol=5e-2)
+    # the centroid VALUES are pinned at 1e-5 in tests/test_gpu_bank_r02.py::test_rebuild_means_exact_given_the_assignment
+    # (same assignment in, same means out); here the two runs may differ in a few boundary rows
+    same_counts = hf.centroid_counts.cpu() == ob.centroid_counts
+    assert float(same_counts.float().mean()) >= 0.9
 
 
 def test_gather_and_state_dict_roundtrip(dev):
@@ -410,12 +412,14 @@ def test_two_stage_equals_fp32_scan(dev, N, D, nq, k, kind):
     if D % 8 == 0:                                   # prefilter over the bf16 shadow of the bank
         from aura_snn_rag_amd import ops
         b = bank.to(dev).contiguous()
-        shadow = torch.empty(N, D, dtype=torch.bfloat16, device=dev)
-        ops.bank_shadow_update(b, shadow)
-        assert torch.equal(shadow, b.to(torch.bfloat16))
         inv = torch.empty(N, device=dev)
         ops.bank_row_norms(b, inv, 0, N)
-        s2, i2 = ops.knn_search(b, inv, meta.to(dev).contiguous(), q.to(dev).contiguous(), k, NOW, shadow=shadow)
+        shadow, rho = ops.make_shadow(b, inv)
+        xn = b * inv.unsqueeze(1)
+        assert torch.equal(shadow, xn.to(torch.bfloat16))               # the normalised rows, rounded
+        resid = (shadow.float() - xn).norm(dim=1)
+        assert bool((rho >= resid).all()) and bool((rho <= 2.0 ** -8 + 1e-3).all())
+        s2, i2 = ops.knn_search(b, inv, meta.to(dev).contiguous(), q.to(dev).contiguous(), k, NOW, shadow=shadow, rho=rho)
         assert torch.equal(i0, i2) and torch.equal(s0, s2)
 
 
@@ -436,24 +440,24 @@ def test_two_stage_centroid_candidates(dev, N, D, nq, k):
     meta[::97, 2] = -1.0                                                      # rows without a centroid
     q = _queries(bank.cpu(), nq, g).to(dev).contiguous()
     q[0] = 0.0                                                                # probes the zero centroids: no rows
-    shadow = torch.empty(N, D, dtype=torch.bfloat16, device=dev); ops.bank_shadow_update(bank, shadow)
+    shadow, rho = ops.make_shadow(bank, inv)
     s0, i0 = ops.knn_search(bank, inv, meta, q, k, NOW, centroids=cent, nprobe=8, fp32_scan=True)
-    s1, i1 = ops.knn_search(bank, inv, meta, q, k, NOW, centroids=cent, nprobe=8, shadow=shadow)
+    s1, i1 = ops.knn_search(bank, inv, meta, q, k, NOW, centroids=cent, nprobe=8, shadow=shadow, rho=rho)
     assert torch.equal(i0, i1) and torch.equal(s0, s1)
     assert (i0 >= 0).any() and (i0[:, -1] < 0).any() or True
 
 
 def test_two_stage_random_sweep(dev):
     """16 random (N, D, nq, k, data kind, metadata kind) cases: both prefilter sources must agree
-    with the all-fp32 scan bit for bit (tools/two_stage_fuzz.py runs longer sweeps)."""
-    from tools.two_stage_fuzz import sweep
+    with the all-fp32 scan bit for bit (tests/fuzz_two_stage.py runs longer sweeps)."""
+    from tests.fuzz_two_stage import sweep
     assert sweep(cases=16, seed=2026, dev=dev, verbose=False) == 0
 
 
 def test_inverted_lists_random_sweep(dev):
     """12 random (N, D, nq, k, centroid count, metadata) cases of the inverted lists on the two-stage scan
-    against the masked fp32 scan (tools/ivf2_fuzz.py runs longer sweeps)."""
-    from tools.ivf2_fuzz import sweep
+    against the masked fp32 scan (tests/fuzz_ivf2.py runs longer sweeps)."""
+    from tests.fuzz_ivf2 import sweep
     assert sweep(cases=12, seed=77, dev=dev, verbose=False) == 0
 
 
@@ -488,7 +492,7 @@ def test_bank_shadow_follows_writes(dev):
     b.memory_metadata.copy_(a.memory_metadata)
     assert a.memory_count == M
     same(now)
-    assert torch.equal(a._shadow[:M], a.memory_features[:M].to(torch.bfloat16))
+    assert torch.equal(a._shadow[:M], (a.memory_features[:M] * a._inv_norm[:M].unsqueeze(1)).to(torch.bfloat16))
     a.memory_features[:100].mul_(-1.0)                              # direct edit + documented refresh
     b.memory_features[:100].mul_(-1.0)
     a.refresh_norms(); b.refresh_norms()
@@ -528,11 +532,15 @@ def test_inverted_lists_two_stage(dev, N, D, nq, k, ncent):
     if ncent < 256:
         q[0] = 0.0                                                  # nearest centroids: the zero rows, no lists
     order, off, lens = _lists_of(meta, N)
-    srows, pad_off = ops.ivf2_layout(order, off, lens)
-    assert int(pad_off[256]) == srows.numel() and srows.numel() % 16 == 0
+    st = ops.build_ivf2(bank, inv, meta[:, 2], slack=0 if nq % 2 else 48)
+    srows, pad_off = st["sorted_rows"], st["pad_off"]
+    assert int(pad_off[256]) <= st["n_sorted"] <= srows.numel() and st["n_sorted"] % 16 == 0
+    assert bool((pad_off % 16 == 0).all()) and torch.equal(st["list_len"], lens)
     assert torch.equal(torch.sort(srows[srows >= 0]).values, torch.sort(order[int(off[0]):]).values)
-    sshadow = ops.bank_shadow_sorted(bank, srows)
-    s1, r1, o1 = ops.knn_search_ivf2(bank, inv, meta, q, k, NOW, cent, 8, sshadow, srows, pad_off, lens)
+    listed = torch.nonzero(srows >= 0).flatten()
+    assert torch.equal(st["pos_of_row"][srows[listed].long()].long(), listed)
+    s1, r1, o1 = ops.knn_search_ivf2(bank, inv, meta, q, k, NOW, cent, 8, st["sorted_bf16"], st["rho"], srows, pad_off,
+                                     st["list_len"], n_sorted=st["n_sorted"])
     flag = int(o1.item())                 # read before the next search resets the shared flag
     s0, r0 = ops.knn_search(bank, inv, meta, q, k, NOW, centroids=cent, nprobe=8, fp32_scan=True)
     if flag != 0:
@@ -603,7 +611,7 @@ def test_product_centroid_recall_paths_agree(dev):
     q2 = feats[torch.randint(0, 10000, (700,), generator=g)] + 0.1 * torch.randn(700, D, generator=g)
     sa, ra = a.recall_batch(q2, k=9, now=now)
     sb, rb = b.recall_batch(q2, k=9, now=now)
-    assert a._lists2 is not None and b._lists2 is None
+    assert a._ivf is not None and a._ivf.valid and b._ivf is None
     assert torch.equal(ra, rb) and torch.equal(sa, sb)
     a.create_episodic_memories([f"n{i}" for i in range(64)], feats[:64] * 1.01)   # lists change
     b.create_episodic_memories([f"n{i}" for i in range(64)], feats[:64] * 1.01)
@@ -629,11 +637,11 @@ def test_two_stage_ties_and_overflow_fallback(dev):
     assert torch.equal(i, i0) and torch.equal(s, s0)
     # the flag itself: without the wrapper's retry the overflow is reported, not hidden
     _search(dev, bank, meta, q, 40, check_overflow=False)
-    assert int(ops._ovf_flags[torch.device(dev)].item()) != 0     # bit 8: more survivors than the refine kernel holds
+    assert int(ops._overflow_flag(torch.device(dev)).item()) != 0     # bit 8: more survivors than the refine kernel holds
     # moderate duplication (fits the lists): exact without any fallback
     bank2 = torch.randn(N, D, generator=g)
     bank2[100:160] = bank2[100]
     q2 = (bank2[100] + 0.01 * torch.randn(2, D, generator=g)).contiguous()
     s2, i2 = _search(dev, bank2, meta, q2, 20, check_overflow=False)
-    assert int(ops._ovf_flags[torch.device(dev)].item()) == 0
+    assert int(ops._overflow_flag(torch.device(dev)).item()) == 0
     assert i2[0].tolist() == list(range(100, 120))
