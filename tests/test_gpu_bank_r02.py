@@ -188,8 +188,9 @@ def test_inverted_lists_follow_writes_incrementally(dev):
         # the rows just written are found through the lists
         s, r = a.recall_batch(new[:5].to(dev).repeat(120, 1), k=1, now=now)
         assert bool((r[:5, 0] >= 10200).all())
+        fill = draw(M - 10240)
         for hf in (a, b):                                            # fill the bank, then overwrite rows 0.. (holes)
-            hf.create_episodic_memories([f"f{i}" for i in range(M - 10240)], draw(M - 10240))
+            hf.create_episodic_memories([f"f{i}" for i in range(M - 10240)], fill)
         same()
         n_packs = len(packs)
         assert n_packs >= 1                                          # 3760 rows > slack: re-packed once at the recall
