@@ -48,7 +48,7 @@ SIGNATURES = {
     "aura_bank_gather": (I, [P, I64, P, P, I64, I64, P]),
     "aura_kmeans_assign": (I, [P, P, P, P, I64, I64, I, P]),
     "aura_kmeans_means_workspace_bytes": (I64, [I64, I64, I]),
-    "aura_kmeans_segment_means": (I, [P, P, P, P, P, I64, I64, I64, I, P]),
+    "aura_kmeans_segment_means": (I, [P, P, P, P, P, I64, I64, I64, I, I, P]),
     "aura_kmeans_commit": (I, [P, P, P, P, I64, I, P]),
     "aura_addition_linear": (I, [P, P, P, P, I64, I64, I64, P]),
     "aura_gif_train_forward": (I, [P, P, P, P, P, P, F, I, F, F, I64, I64, I64, P]),

@@ -392,17 +392,42 @@ class HippocampalFormation(nn.Module):
     def _write_rows(self, ids: Sequence[str], feats: torch.Tensor, now: float) -> None:
         """Write a run of rows that contains no centroid-rebuild boundary."""
         slots, n_app, new_count, new_cursor = self._plan_slots(len(ids))
+        self._store_rows(ids, feats, slots, n_app, new_count, new_cursor, now,
+                         online=self.use_centroid_index and self._index_ready)
+
+    def write_at(self, ids: Sequence[str], feats: torch.Tensor, slots: np.ndarray, n_app: int, now: float,
+                 cids: Optional[torch.Tensor] = None) -> None:
+        """Positioned write, the building block of a row-sharded bank (``sharded.ShardedHippocampus``):
+        row i goes to local slot ``slots[i]``; the first ``n_app`` slots extend the bank
+        (``memory_count .. memory_count + n_app - 1``), the rest overwrite.  No centroid update happens
+        here: ``cids`` (fp32 [n], device) are the centroid ids the caller assigned against the
+        replicated centroid table (None: -1, "no list")."""
+        feats = self._features_to_device(feats)
+        slots = np.ascontiguousarray(slots, dtype=np.int64)
+        if feats.shape[0] != len(ids) or slots.size != len(ids):
+            raise ValueError("write_at: ids, feats and slots disagree")
+        if slots.size == 0:
+            return
+        if n_app and not np.array_equal(slots[:n_app], np.arange(self.memory_count, self.memory_count + n_app)):
+            raise ValueError("write_at: the appended slots must continue the bank")
+        if slots.min() < 0 or slots.max() >= self.max_memories or slots[n_app:].max(initial=-1) >= self.memory_count + n_app:
+            raise ValueError("write_at: slot out of range")
+        self._store_rows(ids, feats, slots, n_app, self.memory_count + n_app, self._write_cursor, now,
+                         online=False, cids=cids)
+
+    def _store_rows(self, ids, feats, slots: np.ndarray, n_app: int, new_count: int, new_cursor: int, now: float,
+                    online: bool, cids: Optional[torch.Tensor] = None) -> None:
         c0 = self.memory_count
         slot_t = torch.from_numpy(slots).to(self.device)
-        online = self.use_centroid_index and self._index_ready
         eff_k = min(self.centroids_k, self.centroids.shape[0])
         # A batch that overwrites may name a slot more than once (a full bank in the reference's mode
         # sends every write to slot 0): the last write wins, as in the reference's sequential loop.  The
         # serial centroid kernel walks the rows in order; the parallel kernel gets the survivors only.
         keep = self._last_occurrences(slots, n_app)
-        uniq_t = slot_t if keep is None else slot_t[torch.from_numpy(keep).to(self.device)]
+        keep_t = None if keep is None else torch.from_numpy(keep).to(self.device)
+        uniq_t = slot_t if keep is None else slot_t[keep_t].contiguous()
         if keep is not None and not online:
-            feats_w, slot_w = feats[torch.from_numpy(keep).to(self.device)].contiguous(), uniq_t.contiguous()
+            feats_w, slot_w = feats[keep_t].contiguous(), uniq_t
         else:
             feats_w, slot_w = feats, slot_t
         ops.bank_write(self.memory_features, self.memory_locations, self.memory_metadata,
@@ -412,8 +437,11 @@ class HippocampalFormation(nn.Module):
                        centroids=self.centroids if online else None,
                        centroid_counts=self.centroid_counts if online else None,
                        eff_k=eff_k if online else 0)
+        if cids is not None:
+            c = cids.to(device=self.device, dtype=torch.float32)
+            self.memory_metadata[uniq_t, 2] = c if keep is None else c[keep_t]
         self.memory_count, self._write_cursor = new_count, new_cursor
-        self._after_write(slot_t, uniq_t.contiguous(), slots, c0, n_app)
+        self._after_write(slot_t, uniq_t, slots, c0, n_app)
         self._slot_time[slots] = time.time()
         slot_list = slots.tolist()
         self.id_to_idx.update(zip(ids, slot_list))
@@ -494,8 +522,8 @@ class HippocampalFormation(nn.Module):
 
     def recall_batch(self, queries: torch.Tensor, k: int = 5,
                      locations: Optional[torch.Tensor] = None, now: Optional[float] = None,
-                     use_candidates: Optional[bool] = None, check_overflow: bool = True
-                     ) -> Tuple[torch.Tensor, torch.Tensor]:
+                     use_candidates: Optional[bool] = None, check_overflow: bool = True,
+                     fallback_empty: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
         """Batched recall: ``(scores [nq, k'], rows [nq, k'])`` with ``k' = min(k, count)``;
         rows are bank row indices (int32), ``-1`` where a query has fewer than ``k'`` candidates.
 
@@ -503,7 +531,9 @@ class HippocampalFormation(nn.Module):
         prefilter's overflow flag (candidate lists that did not fit: the call is re-run on the fp32
         path, same results) and, in candidate mode, whether some query was left without candidates
         (it then falls back to the full scan, reference ``:269-270``).  Pass False only inside
-        latency-critical loops whose data is known to be well behaved."""
+        latency-critical loops whose data is known to be well behaved.  ``fallback_empty=False``
+        leaves such queries at ``-1`` (a shard of a row-sharded bank: the query may have candidates
+        on another shard, so the fallback is the caller's decision after the merge)."""
         if self.memory_count == 0:
             z = torch.empty(queries.shape[0], 0, device=self.device)
             return z, z.to(torch.int32)
@@ -556,7 +586,7 @@ class HippocampalFormation(nn.Module):
                                  empty.any()]).tolist()
             if flags[0]:
                 scores = rows = None                  # candidate lists too long: the fp32 paths below
-            elif not flags[1]:
+            elif not flags[1] or not fallback_empty:
                 return scores, rows
         if scores is None and q_loc is None and full_index:
             # fp32 inverted lists: every probed list is streamed once per batch
@@ -570,7 +600,7 @@ class HippocampalFormation(nn.Module):
         if scores is None:
             scores, rows = ops.knn_search(self.memory_features, self._inv_norm, self.memory_metadata,
                                           q, kk, now, centroids=self.centroids, nprobe=nprobe, **kw)
-        if not check_overflow:
+        if not check_overflow or not fallback_empty:
             return scores, rows
         # a query whose probed centroids own no rows falls back to the full scan (ref :269-270)
         empty = (rows[:, 0] < 0)

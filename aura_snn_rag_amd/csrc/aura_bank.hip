@@ -211,7 +211,8 @@ __global__ __launch_bounds__(256) void kmeans_partial_kernel(const float* __rest
 
 __global__ __launch_bounds__(256) void kmeans_reduce_kernel(const float* __restrict__ partial,
                                                             const int32_t* __restrict__ seg_off,
-                                                            float* __restrict__ centroids, int64_t D, int k) {
+                                                            float* __restrict__ centroids, int64_t D, int k,
+                                                            int sums_only) {
     __shared__ int s_pref[257];
     km_item_prefix(seg_off, k, s_pref);
     const int lane = threadIdx.x & 63;
@@ -220,13 +221,17 @@ __global__ __launch_bounds__(256) void kmeans_reduce_kernel(const float* __restr
         const int c = w / slices;
         const int64_t col = (int64_t)(w - c * slices) * 256 + lane * 4;
         const int len = seg_off[c + 1] - seg_off[c];
-        if (len <= 0 || col >= D) continue;                 // empty clusters keep their centroid (:362-363)
+        if (col >= D) continue;
+        if (len <= 0) {                                     // empty clusters keep their centroid (:362-363);
+            if (sums_only) *reinterpret_cast<float4*>(centroids + (int64_t)c * D + col) = make_float4(0.f, 0.f, 0.f, 0.f);
+            continue;                                       // as a partial sum an empty cluster is zero
+        }
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int it = s_pref[c]; it < s_pref[c + 1]; ++it) {
             const float4 x = *reinterpret_cast<const float4*>(partial + (int64_t)it * D + col);
             s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w;
         }
-        const float inv = (float)len;
+        const float inv = sums_only ? 1.0f : (float)len;
         *reinterpret_cast<float4*>(centroids + (int64_t)c * D + col) =
             make_float4(s.x / inv, s.y / inv, s.z / inv, s.w / inv);
     }
@@ -297,7 +302,7 @@ int64_t aura_kmeans_means_workspace_bytes(int64_t N, int64_t D, int k) {
 
 int aura_kmeans_segment_means(const float* bank, const int32_t* order, const int32_t* seg_off, float* centroids,
                               void* workspace, int64_t workspace_bytes, int64_t N, int64_t D, int k,
-                              void* stream) {
+                              int sums_only, void* stream) {
     if (N < 0 || N > 0x7ffffff0LL || D <= 0 || (D & 3) || k <= 0 || k > 256) return AURA_E_INVAL;
     if (N == 0) return AURA_OK;
     if (!bank || !order || !seg_off || !centroids || !workspace) return AURA_E_INVAL;
@@ -315,7 +320,7 @@ int aura_kmeans_segment_means(const float* bank, const int32_t* order, const int
     if (rc) return rc;
     const int64_t waves = (int64_t)k * ((D + 255) / 256);
     hipLaunchKernelGGL(kmeans_reduce_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s,
-                       static_cast<const float*>(workspace), seg_off, centroids, D, k);
+                       static_cast<const float*>(workspace), seg_off, centroids, D, k, sums_only);
     return check_launch_b();
 }
 

@@ -604,8 +604,9 @@ def group_by_cluster(assign, k: int = 256) -> Tuple[torch.Tensor, torch.Tensor]:
     return order, seg_off
 
 
-def kmeans_segment_means(bank, order, seg_off, centroids, k: int) -> None:
-    """centroids[c] = mean of bank[order[seg_off[c]:seg_off[c+1]]] for c < k (empty clusters keep theirs)."""
+def kmeans_segment_means(bank, order, seg_off, centroids, k: int, sums_only: bool = False) -> None:
+    """centroids[c] = mean of bank[order[seg_off[c]:seg_off[c+1]]] for c < k (empty clusters keep theirs);
+    ``sums_only``: the sums instead (zeros for empty clusters) -- a shard's partial result."""
     _need(bank, "bank", torch.float32); _need(centroids, "centroids", torch.float32)
     _need(order, "order", torch.int32); _need(seg_off, "seg_off", torch.int32)
     M, D = bank.shape
@@ -617,7 +618,7 @@ def kmeans_segment_means(bank, order, seg_off, centroids, k: int) -> None:
     ws = _workspace(bank.device, nbytes)
     base = (ws.data_ptr() + 255) // 256 * 256
     check(L.aura_kmeans_segment_means(_p(bank), _p(order), _p(seg_off), _p(centroids), base, nbytes, N, D, k,
-                                      _stream()), "aura_kmeans_segment_means")
+                                      1 if sums_only else 0, _stream()), "aura_kmeans_segment_means")
 
 
 def kmeans_commit(assign, seg_off, meta, counts, k: int) -> None:

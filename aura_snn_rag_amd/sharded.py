@@ -81,18 +81,231 @@ class ShardedRecall:
         return self.merge(gs, gr, k)
 
 
-def hip_sharded_recall(hippocampus, row_base: int, now: Optional[float] = None, group=None) -> ShardedRecall:
-    """Product wiring: local scan = the HIP kNN over this rank's ``HippocampalFormation`` shard
-    (rows reported with ``idx_base = row_base``), merge = ``aura_topk_merge``."""
-    from . import ops
-    import time as _time
+class ShardedHippocampus:
+    """A row-sharded episodic bank: rank g owns the global rows
+    ``[g * R, (g + 1) * R)`` (``R = local.max_memories``) in its own ``HippocampalFormation``; the
+    256-row centroid table is replicated.  Every method is COLLECTIVE: all ranks call it with the same
+    arguments (the serving layout: writes and queries are visible to every rank; ``recall_batch`` can
+    all-gather per-rank query blocks first).
 
-    def local_search(q, k):
-        hippocampus._ensure_norms()
-        return ops.knn_search(hippocampus.memory_features, hippocampus._inv_norm,
-                              hippocampus.memory_metadata, q.contiguous(), k,
-                              _time.time() if now is None else now,
-                              count=hippocampus.memory_count, idx_base=row_base,
-                              check_overflow=True)
+    * ``write``: slots are planned globally exactly as the single bank plans them (append, then the
+      reference's slot-0 overwrite or the FIFO ring); the owner of a slot (``slot // R``) stores the
+      row.  With the index ready every rank runs the reference's order-dependent nearest-centroid /
+      running-mean update (``hippocampal.py:218-230``) over ALL rows of the batch on its replica of the
+      table -- 256 x D per row, no communication, bit-identical replicas -- and owners record the ids.
+    * ``rebuild_centroids`` (``:345-377``): initial centroids = rows ``perm[:k]`` gathered by
+      all-reduce (each row has exactly one owner), local assign, local per-cluster partial sums and
+      counts, ONE all-reduce of ``k x D + k`` floats, means, second local assign, counts all-reduced.
+    * ``recall_batch``: local recall (the shard's own prefilter shadow / inverted lists, candidate
+      mode included) -> global row ids -> all-gather of ``nq * k * 8`` bytes per rank -> merge.
 
-    return ShardedRecall(local_search, ops.topk_merge, group)
+    ``ops`` is injected (the HIP ops in the product, the CPU stand-ins in the gloo tests)."""
+
+    def __init__(self, local, total_rows: int, ops_module=None, group=None, now_fn=None):
+        import time as _time
+        from . import ops as _ops
+        self.local = local
+        self.ops = _ops if ops_module is None else ops_module
+        self.group = group
+        self.R = int(local.max_memories)
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.total_rows = int(total_rows)
+        if self.R * self.world < self.total_rows:
+            raise ValueError("shards too small for total_rows")
+        self.row_base = self.rank * self.R
+        self.memory_count = 0                      # global
+        self._write_cursor = 0
+        self._now = _time.time if now_fn is None else now_fn
+        self._recall = ShardedRecall(self._local_search, self.ops.topk_merge, group)
+        self._recall_kw = {}
+
+    # ------------------------------------------------------------------ helpers
+    def _all_reduce(self, t: torch.Tensor) -> torch.Tensor:
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def _local_count(self, global_count: int) -> int:
+        return max(0, min(self.R, global_count - self.row_base))
+
+    @property
+    def use_centroid_index(self) -> bool:
+        return self.local.use_centroid_index
+
+    # ------------------------------------------------------------------ write
+    def write(self, memory_ids, features) -> None:
+        """Collective batched write: identical to ``HippocampalFormation.create_episodic_memories`` on one
+        bank of ``total_rows`` rows, including the rebuild every ``centroids_update_interval`` inserts."""
+        import numpy as np
+        loc = self.local
+        feats = loc._features_to_device(features)
+        n = len(memory_ids)
+        if feats.shape[0] != n:
+            raise ValueError(f"{n} ids but {feats.shape[0]} feature rows")
+        M = self.total_rows
+        i = 0
+        while i < n:
+            run = n - i
+            if loc.use_centroid_index:
+                interval = max(1, int(loc.centroids_update_interval))
+                if self.memory_count < M:
+                    run = min(run, interval - (self.memory_count % interval), M - self.memory_count)
+                elif self.memory_count % interval == 0 and self.memory_count > loc.centroids_k:
+                    run = 1
+            ids_r, f_r = memory_ids[i:i + run], feats[i:i + run]
+            # global slots, as HippocampalFormation._plan_slots
+            count = self.memory_count
+            n_app = min(run, max(M - count, 0))
+            slots = np.empty(run, dtype=np.int64)
+            slots[:n_app] = np.arange(count, count + n_app)
+            rest = run - n_app
+            if rest:
+                if loc._overflow == 'reference':
+                    slots[n_app:] = 0
+                else:
+                    slots[n_app:] = (self._write_cursor + np.arange(rest)) % M
+                    self._write_cursor += rest
+            now = self._now()
+            cids = None
+            if loc.use_centroid_index and loc._index_ready:
+                # the reference's sequential centroid update over the WHOLE run on this rank's replica: the
+                # rows pass through a scratch bank (only their centroid ids and the table's new state matter)
+                dev, D = feats.device, feats.shape[1]
+                sd = loc.memory_locations.shape[1]
+                s_bank = torch.empty(run, D, device=dev); s_loc = torch.empty(run, sd, device=dev)
+                s_meta = torch.empty(run, 4, device=dev); s_inv = torch.empty(run, device=dev)
+                self.ops.bank_write(s_bank, s_loc, s_meta, s_inv, f_r.contiguous(),
+                                    torch.arange(run, dtype=torch.int64, device=dev),
+                                    loc.current_location.to(device=dev, dtype=torch.float32).contiguous(), now,
+                                    centroids=loc.centroids, centroid_counts=loc.centroid_counts,
+                                    eff_k=min(loc.centroids_k, loc.centroids.shape[0]))
+                cids = s_meta[:, 2].contiguous()
+            own = (slots // self.R) == self.rank
+            if own.any():
+                idx = np.nonzero(own)[0]
+                idx_t = torch.from_numpy(idx).to(feats.device)
+                n_app_local = int(own[:n_app].sum())
+                loc.write_at([ids_r[j] for j in idx], f_r[idx_t], slots[idx] - self.row_base, n_app_local, now,
+                             cids=None if cids is None else cids[idx_t])
+            self.memory_count = count + n_app
+            i += run
+            if (loc.use_centroid_index and self.memory_count % loc.centroids_update_interval == 0
+                    and self.memory_count > loc.centroids_k):
+                self.rebuild_centroids()
+
+    def bulk_write(self, features, first_index: int = 0, id_prefix: str = "bulk-") -> int:
+        """Seeding path: every rank passes ITS OWN rows (already routed: e.g. rank g reads the g-th slice
+        of the corpus); rows are appended to the local shard, no centroid update.  Returns the new global
+        count; call ``rebuild_centroids`` once at the end.  Shards must be filled evenly by the caller
+        (global row ids are ``rank * R + local row``)."""
+        self.local.bulk_write(features, id_prefix=id_prefix, first_index=first_index, rebuild=False)
+        c = torch.tensor([float(self.local.memory_count)], device=self.local.memory_features.device)
+        self.memory_count = int(self._all_reduce(c).item())
+        return self.memory_count
+
+    # ------------------------------------------------------------------ rebuild
+    def rebuild_centroids(self, perm: Optional[torch.Tensor] = None) -> None:
+        loc, ops = self.local, self.ops
+        if not loc.use_centroid_index:
+            return
+        dev = loc.memory_features.device
+        n_loc = loc.memory_count
+        # global row ids of the local rows; with evenly filled shards (bulk_write) the global count is
+        # world * n_loc, with the slot-ordered write path it is self.memory_count
+        n_glob = int(self._all_reduce(torch.tensor([float(n_loc)], device=dev)).item())
+        if n_glob == 0:
+            return
+        k = min(loc.centroids_k, n_glob)
+        if perm is None:
+            perm = torch.randperm(n_glob)
+            if self.world > 1:                     # rank 0's draw, as one process would draw it
+                p = perm.to(dev)
+                dist.broadcast(p, src=0, group=self.group)
+                perm = p.cpu()
+        # initial centroids: perm indexes the ACTIVE rows in global order (shard after shard)
+        counts_all = torch.zeros(self.world, device=dev)
+        counts_all[self.rank] = float(n_loc)
+        counts_all = self._all_reduce(counts_all).long().cpu()
+        starts = torch.cumsum(counts_all, 0) - counts_all          # first active index of every rank
+        pk = perm[:k].long()
+        mine = (pk >= starts[self.rank]) & (pk < starts[self.rank] + n_loc)
+        init = torch.zeros(loc.centroids.shape, device=dev)
+        if bool(mine.any()):
+            rows = (pk[mine] - starts[self.rank]).to(device=dev, dtype=torch.int32)
+            init[torch.nonzero(mine).flatten().to(dev)] = ops.bank_gather(loc.memory_features, rows)
+        cent = self._all_reduce(init)              # each of the k rows has exactly one owner: x + 0 + ... = x
+        D = cent.shape[1]
+        K = cent.shape[0]                            # rows of the (replicated) centroid table
+        sums = torch.zeros(K, D, device=dev)
+        cnt = torch.zeros(K, device=dev)
+        if n_loc:
+            assign = ops.kmeans_assign(loc.memory_features, cent, n_loc, k)
+            order, seg_off = ops.group_by_cluster(assign, k)
+            ops.kmeans_segment_means(loc.memory_features, order, seg_off, sums, k, sums_only=True)
+            cnt[:k] = (seg_off[1:k + 1] - seg_off[:k]).to(torch.float32)
+        packed = self._all_reduce(torch.cat([sums, cnt.unsqueeze(1)], dim=1))
+        sums, cnt = packed[:, :D], packed[:, D]
+        has = (cnt > 0).unsqueeze(1)
+        cent = torch.where(has, sums / cnt.clamp(min=1.0).unsqueeze(1), cent)     # empty clusters keep theirs
+        cent[k:] = 0
+        loc.centroids.copy_(cent)
+        cnt2 = torch.zeros(loc.centroids_k, device=dev)
+        pending = None
+        if n_loc:
+            assign = ops.kmeans_assign(loc.memory_features, loc.centroids, n_loc, k)
+            pending = ops.kmeans_update(loc.memory_features, assign, loc.centroids, k, counts=cnt2,
+                                        meta=loc.memory_metadata, update_means=False)
+        loc.centroid_counts = self._all_reduce(cnt2)
+        loc._index_ready = True
+        loc._invalidate_lists()
+        if pending is not None and k == 256 and pending[1].numel() == 257:
+            loc._ivf_pending = pending
+
+    # ------------------------------------------------------------------ recall
+    def _local_search(self, q, k):
+        loc = self.local
+        kk = k
+        if loc.memory_count == 0:
+            s = torch.full((q.shape[0], kk), float("-inf"), device=q.device)
+            return s, torch.full((q.shape[0], kk), -1, dtype=torch.int32, device=q.device)
+        s, r = loc.recall_batch(q, k=kk, fallback_empty=False, **self._recall_kw)
+        if s.shape[1] < kk:                        # a shard with fewer than k rows: pad
+            pad = kk - s.shape[1]
+            s = torch.cat([s, torch.full((s.shape[0], pad), float("-inf"), device=s.device)], dim=1)
+            r = torch.cat([r, torch.full((r.shape[0], pad), -1, dtype=torch.int32, device=r.device)], dim=1)
+        r = torch.where(r >= 0, r + self.row_base, r)
+        s = torch.where(r >= 0, s, torch.full_like(s, float("-inf")))
+        return s.contiguous(), r.contiguous()
+
+    def recall_batch(self, queries: torch.Tensor, k: int = 5, now: Optional[float] = None,
+                     all_gather_queries: bool = False, use_candidates: Optional[bool] = None,
+                     check_overflow: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Global top-k ``(scores [nq, k], GLOBAL rows [nq, k])`` (``-1`` where fewer than k rows can
+        score).  ``all_gather_queries``: every rank brings its own ``nq`` queries and receives their
+        results (the serving layout of ``bench.py --gpus N``)."""
+        q = self.local._features_to_device(queries)
+        self._recall_kw = dict(now=self._now() if now is None else now, use_candidates=use_candidates,
+                               check_overflow=check_overflow)
+        nq = q.shape[0]
+        if all_gather_queries and self.world > 1:
+            # every rank sees every query block: the merged result (and the empty-candidate decision
+            # below) is then identical on all ranks, so the fallback stays collective-safe
+            allq = torch.empty(self.world * nq, q.shape[1], dtype=q.dtype, device=q.device)
+            dist.all_gather_into_tensor(allq, q.contiguous(), group=self.group)
+        else:
+            allq = q
+        s, r = self._recall.recall(allq, int(k))
+        cand = self.local._candidate_mode() if use_candidates is None else (use_candidates and self.local._candidate_mode())
+        if cand and check_overflow and bool((r[:, 0] < 0).any()):
+            # no shard had a candidate for these queries: the reference falls back to the full scan (:269-270)
+            sel = torch.nonzero(r[:, 0] < 0).flatten()
+            self._recall_kw["use_candidates"] = False
+            s2, r2 = self._recall.recall(allq[sel].contiguous(), int(k))
+            s[sel], r[sel] = s2, r2
+        if allq is not q:
+            lo = self.rank * nq
+            s, r = s[lo:lo + nq].contiguous(), r[lo:lo + nq].contiguous()
+        return s, r
+
+

@@ -194,8 +194,10 @@ int aura_topk_merge(const float* in_scores, const int32_t* in_idx, int S, int64_
  * segment_means: the masked means of :358-363 as a segmented reduction.  The caller groups the rows
  *   by cluster (a stable sort of assign): order [N] int32 row ids, seg_off [k+1] int32 with
  *   order[seg_off[c] .. seg_off[c+1]) = rows of cluster c.  centroids[c] = mean of those rows, summed
- *   in a fixed order (reproducible); empty clusters keep their centroid (:362-363).  Reads the bank
- *   once.  D % 4 == 0; workspace: aura_kmeans_means_workspace_bytes(N, D, k) bytes, 16-byte aligned.
+ *   in a fixed order (reproducible); empty clusters keep their centroid (:362-363).  With sums_only
+ *   the per-cluster SUMS are written instead (zeros for empty clusters): a rank's partial result
+ *   of a row-sharded bank, all-reduced with the counts.  Reads the bank once.
+ *   D % 4 == 0; workspace: aura_kmeans_means_workspace_bytes(N, D, k) bytes, 16-byte aligned.
  * commit: meta[i][2] = assign[i] for i < N and counts[c] = seg_off[c+1] - seg_off[c] (counts may be
  *   NULL) -- the recount / metadata write of :370-376. */
 int aura_kmeans_assign(const float* bank, const float* centroids, float* cnorm2_ws,
@@ -203,7 +205,7 @@ int aura_kmeans_assign(const float* bank, const float* centroids, float* cnorm2_
 int64_t aura_kmeans_means_workspace_bytes(int64_t N, int64_t D, int k);
 int aura_kmeans_segment_means(const float* bank, const int32_t* order, const int32_t* seg_off, float* centroids,
                               void* workspace, int64_t workspace_bytes, int64_t N, int64_t D, int k,
-                              void* stream);
+                              int sums_only, void* stream);
 int aura_kmeans_commit(const int32_t* assign, const int32_t* seg_off, float* meta, float* counts, int64_t N,
                        int k, void* stream);
 

@@ -108,6 +108,15 @@ def kmeans_update(bank, assign, centroids, k, counts=None, meta=None, update_mea
     return group_by_cluster(assign, k)
 
 
+def kmeans_segment_means(bank, order, seg_off, centroids, k, sums_only=False):
+    for c in range(k):
+        rows = order[int(seg_off[c]):int(seg_off[c + 1])].long()
+        if rows.numel():
+            centroids[c] = bank[rows].sum(dim=0) if sums_only else bank[rows].mean(dim=0)
+        elif sums_only:
+            centroids[c] = 0
+
+
 def ivf2_slack(update_interval):
     return (min(max(int(update_interval), 64), 512) + 15) // 16 * 16
 

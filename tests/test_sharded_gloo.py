@@ -67,3 +67,100 @@ def test_two_rank_sharded_recall_matches_single_process(tmp_path):
     for rank in range(2):
         s2, i2 = torch.load(out + f".own{rank}")
         assert torch.equal(i2.long(), ri[rank * 5:(rank + 1) * 5])
+
+
+# ----------------------------------------------------------------------------------------------
+# Sharded writes (owner by slot), the centroid rebuild as partial sums + all_reduce, and recall in
+# candidate mode over the shards -- against ONE bank holding everything.
+# ----------------------------------------------------------------------------------------------
+def _clustered_rows(n, D, seed):
+    g = torch.Generator().manual_seed(seed)
+    c = torch.randn(12, D, generator=g) * 4
+    return c[torch.randint(0, 12, (n,), generator=g)] + 0.4 * torch.randn(n, D, generator=g)
+
+
+def _bank_kw(D, M):
+    return dict(n_place_cells=4, n_time_cells=3, n_grid_cells=3, max_memories=M, feature_dim=D, device="cpu",
+                use_centroid_index=True, overflow="fifo")
+
+
+def _run_single_bank(feats, q, perm, D, M, interval, ck, extra):
+    """The same sequence of operations on one HippocampalFormation holding all rows."""
+    from aura_snn_rag_amd.core import hippocampal as H
+    H.ops = stub
+    H.time.time = lambda: NOW
+    hf = H.HippocampalFormation(**_bank_kw(D, M))
+    hf.centroids_k, hf.centroids_update_interval = ck, 10 ** 9     # rebuilds are explicit here
+    n0 = feats.shape[0]
+    hf.create_episodic_memories([f"m{i}" for i in range(n0)], feats)
+    hf.rebuild_centroids(perm=perm)
+    hf.create_episodic_memories([f"x{i}" for i in range(extra.shape[0])], extra)     # online centroid updates
+    s_c, r_c = hf.recall_batch(q, k=6, now=NOW)
+    s_e, r_e = hf.recall_batch(q, k=6, now=NOW, use_candidates=False)
+    return hf, (s_c, r_c, s_e, r_e)
+
+
+def _sharded_worker(rank, world, port, out):
+    from aura_snn_rag_amd.core import hippocampal as H
+    from aura_snn_rag_amd.sharded import ShardedHippocampus
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    H.ops = stub
+    H.time.time = lambda: NOW
+    D, M, ck = 16, 1200, 16
+    feats, extra = _clustered_rows(900, D, 1), _clustered_rows(350, D, 2)      # 900 + 350 > M: ring overwrites
+    q = _clustered_rows(14, D, 3)
+    perm = torch.randperm(900, generator=torch.Generator().manual_seed(4))
+    local = H.HippocampalFormation(**_bank_kw(D, M // world))
+    local.centroids_k, local.centroids_update_interval = ck, 10 ** 9
+    sh = ShardedHippocampus(local, M, ops_module=stub, now_fn=lambda: NOW)
+    for i in range(0, 900, 250):                                # batches that straddle the shard boundary
+        sh.write([f"m{j}" for j in range(i, min(i + 250, 900))], feats[i:i + 250])
+    assert sh.memory_count == 900 and local.memory_count == (600 if rank == 0 else 300)
+    sh.rebuild_centroids(perm=perm)
+    sh.write([f"x{i}" for i in range(350)], extra)
+    assert sh.memory_count == M and local.memory_count == 600 and sh._write_cursor == 50
+    s_c, r_c = sh.recall_batch(q, k=6, now=NOW)
+    s_e, r_e = sh.recall_batch(q, k=6, now=NOW, use_candidates=False)
+    myq = q[rank * 7:(rank + 1) * 7].contiguous()
+    s_o, r_o = sh.recall_batch(myq, k=6, now=NOW, all_gather_queries=True)
+    torch.save(dict(feats=local.memory_features.clone(), meta=local.memory_metadata.clone(), cent=local.centroids.clone(),
+                    counts=local.centroid_counts.clone(), res=(s_c, r_c, s_e, r_e), own=(s_o, r_o),
+                    ids=dict(local.id_to_idx)), out + f".{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_writes_rebuild_and_candidate_recall(tmp_path, monkeypatch):
+    out = str(tmp_path / "sh")
+    mp.spawn(_sharded_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    from aura_snn_rag_amd.core import hippocampal as H
+    monkeypatch.setattr(H, "ops", stub)
+    monkeypatch.setattr(H.time, "time", lambda: NOW)
+    D, M, ck = 16, 1200, 16
+    feats, extra = _clustered_rows(900, D, 1), _clustered_rows(350, D, 2)
+    q = _clustered_rows(14, D, 3)
+    perm = torch.randperm(900, generator=torch.Generator().manual_seed(4))
+    hf, (s_c, r_c, s_e, r_e) = _run_single_bank(feats, q, perm, D, M, 10 ** 9, ck, extra)
+    parts = [torch.load(out + f".{r}") for r in range(2)]
+    # owner-by-slot routing: the two shards side by side ARE the single bank
+    assert torch.equal(torch.cat([p["feats"] for p in parts]), hf.memory_features)
+    meta = torch.cat([p["meta"] for p in parts])
+    assert torch.equal(meta[:, :2], hf.memory_metadata[:, :2])
+    # centroid table: replicated, equal on both ranks, and equal to the single bank's up to the
+    # summation order of the all-reduced partial sums
+    assert torch.equal(parts[0]["cent"], parts[1]["cent"]) and torch.equal(parts[0]["counts"], parts[1]["counts"])
+    assert torch.allclose(parts[0]["cent"], hf.centroids, rtol=1e-5, atol=1e-5)
+    assert torch.equal(parts[0]["counts"], hf.centroid_counts)
+    assert torch.equal(meta[:, 2], hf.memory_metadata[:, 2]), "centroid ids of the sharded and the single bank differ"
+    ids = {}
+    for r, p in enumerate(parts):
+        ids.update({k_: v + r * (M // 2) for k_, v in p["ids"].items()})
+    assert ids == hf.id_to_idx
+    # recall: candidate mode and exact, replicated queries and per-rank query blocks
+    ps_c, pr_c, ps_e, pr_e = parts[0]["res"]
+    assert torch.equal(pr_e.long(), r_e.long()) and torch.allclose(ps_e, s_e, atol=1e-6)
+    assert torch.equal(pr_c.long(), r_c.long()) and torch.allclose(ps_c, s_c, atol=1e-6)
+    for r in range(2):
+        s_o, r_o = parts[r]["own"]
+        assert torch.equal(r_o.long(), r_c[r * 7:(r + 1) * 7].long())
