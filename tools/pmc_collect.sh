@@ -1,22 +1,28 @@
 #!/bin/bash
-# Hardware counters per dispatch for bench.py's recall step, in separate rocprofv3 --pmc passes
-# (never combined with tracing domains other than --kernel-trace).  Run on the GPU box from the
-# repo root:  bash tools/pmc_collect.sh   -> gpurun_out/pmc_r01/*.csv + profiles/r01_pmc_per_dispatch.json
+# Hardware counters per dispatch for bench.py's recall steps, in separate rocprofv3 --pmc passes (never
+# combined with tracing domains other than --kernel-trace).  Run on the GPU box from the repo root:
+#   bash tools/pmc_collect.sh   -> gpurun_out/pmc_r02/<config>/<pass>/... + profiles/r02_pmc_per_dispatch.json
 set -e
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$ROOT/gpurun_out/pmc_r01
+OUT=$ROOT/gpurun_out/pmc_r02
 cd /tmp && export TMPDIR=/tmp
 rm -rf $OUT && mkdir -p $OUT
-CMD="python3 $ROOT/bench.py --no-cpu-baseline --no-secondary --steps 8 --warmup 2"
-pass() {  # name, counters...
-  local name=$1; shift
-  timeout -k 10 240 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$name -o p -- $CMD > $OUT/$name.log 2>&1 || { tail -5 $OUT/$name.log; return 1; }
+COMMON="--no-cpu-baseline --no-secondary --steps 6 --warmup 2"
+pass() {  # config, name, bench flags, counters...
+  local cfg=$1 name=$2 flags=$3; shift 3
+  mkdir -p $OUT/$cfg
+  timeout -k 10 400 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$cfg/$name -o p -- python3 $ROOT/bench.py $COMMON $flags > $OUT/$cfg/$name.log 2>&1 || { tail -5 $OUT/$cfg/$name.log; return 1; }
 }
-# FETCH_SIZE (3 TCC counters) and WRITE_SIZE (2) do not fit one pass (MI355X_MICROARCH.md)
-pass fetch FETCH_SIZE
-pass write WRITE_SIZE
-pass busy GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY
-pass valu SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES
-python3 $ROOT/tools/pmc_summarize.py $OUT $ROOT/profiles/r01_pmc_per_dispatch.json
+config() {  # config key, bench flags
+  # FETCH_SIZE (3 TCC counters) and WRITE_SIZE (2) do not fit one pass (MI355X_MICROARCH.md)
+  pass "$1" fetch "$2" FETCH_SIZE
+  pass "$1" write "$2" WRITE_SIZE
+  pass "$1" busy "$2" GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES
+  pass "$1" valu "$2" SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT
+}
+config headline_1000000x768_n1_index ""
+config exact_1000000x768 "--exact --nq 256"
+config config2 "--bank-rows 100000 --nq 256 --exact"
+python3 $ROOT/tools/pmc_summarize.py $OUT $ROOT/profiles/r02_pmc_per_dispatch.json
 # keep only the summary-sized files in gpurun_out
 find $OUT -name "*.csv" -size +8M -delete
