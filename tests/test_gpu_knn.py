@@ -58,6 +58,7 @@ def test_exact_search_matches_oracle(dev, N, D, nq, k):
     for force in (True, False):
         s, i = _search(dev, bank, meta, q, k, force_dense=force)
         exact, n, ok = topk_equivalent(i, s, ri, rs)
+        print(f"\n[{N}x{D} nq={nq} k={k} force_dense={force}] index-exact queries vs oracle: {exact}/{n}", end="")
         assert ok, f"force_dense={force}: mismatch beyond near-tie tolerance"
         assert exact >= n - max(1, n // 50), f"only {exact}/{n} queries index-exact"
     # dense and filter paths must agree bit for bit with each other
@@ -78,6 +79,7 @@ def test_config2_100k_768(dev):
     sub = torch.cat([torch.arange(0, 8), torch.arange(nq - 8, nq)])
     ri, rs = O.knn_exact_batch(bank, meta[:, 0], meta[:, 1], q[sub], k, NOW)
     exact, n, ok = topk_equivalent(i[sub], s[sub], ri, rs)
+    print(f"\n[config 2: 100000x768 nq=256 k=32] index-exact queries vs oracle: {exact}/{n}")
     assert ok and exact >= n - 1
     # planted neighbours: query j < 128 is bank row + noise, so its top-1 must be that row
     # size-independent properties: sorted descending, unique rows, in range

@@ -1,0 +1,127 @@
+"""GPU parity where the metric lives: a 1M x 768 bank on one GPU (exact two-stage recall, centroid
+index through probe masks / inverted lists on the two-stage scan / fp32 lists) and the config-4
+shard shape (125 000 x 768, 2048 queries, idx_base != 0), against the CPU oracle.  Every test prints
+how many queries are index-exact (run with -s to see it; the counts are asserted as well)."""
+import pytest
+import torch
+
+from oracle import aura_oracle as O
+from tests.helpers import topk_equivalent
+
+pytestmark = pytest.mark.gpu
+
+
+def _fill(hf, rows, D, seed, dev, strengths=False):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    for r0 in range(0, rows, 1 << 17):
+        n = min(1 << 17, rows - r0)
+        hf.bulk_write(torch.randn(n, D, generator=g, device=dev), rebuild=False)
+    if strengths:                                       # decayed bank: ranking != cosine ranking
+        hf.memory_metadata[:rows, 0] = 0.5 + 0.5 * torch.rand(rows, generator=g, device=dev)
+
+
+@pytest.fixture(scope="module")
+def bank_1m(dev):
+    from aura_snn_rag_amd.core.hippocampal import HippocampalFormation
+    N, D = 1_000_000, 768
+    hf = HippocampalFormation(feature_dim=D, max_memories=N, n_place_cells=8, n_time_cells=4, n_grid_cells=4,
+                              device="cuda", use_centroid_index=True)
+    _fill(hf, N, D, 1234, dev, strengths=True)
+    hf.rebuild_centroids(perm=torch.randperm(N, generator=torch.Generator().manual_seed(7)))
+    now = float(hf.memory_metadata[0, 1].item()) + 30.0
+    g = torch.Generator(device=dev).manual_seed(5)
+    pick = torch.randint(0, N, (150,), generator=g, device=dev)
+    q = torch.cat([hf.memory_features[pick] + 0.05 * torch.randn(150, D, generator=g, device=dev),
+                   torch.randn(150, D, generator=g, device=dev)]).contiguous()
+    host = dict(bank=hf.memory_features.cpu(), meta=hf.memory_metadata.cpu(), cent=hf.centroids.cpu())
+    yield hf, q, pick, now, host
+    del hf
+    torch.cuda.empty_cache()
+
+
+def test_1m_exact_recall_vs_oracle(bank_1m, dev):
+    """Exact recall at 1M x 768: two-stage (bf16 shadow) == all-fp32 scan bit for bit on 300 queries; the
+    oracle on 12 of them."""
+    from aura_snn_rag_amd import ops
+    hf, q, pick, now, host = bank_1m
+    N, k = hf.memory_count, 32
+    s2, r2 = hf.recall_batch(q, k=k, now=now, use_candidates=False)
+    assert hf._shadow is not None
+    s0, r0 = ops.knn_search(hf.memory_features, hf._inv_norm, hf.memory_metadata, q, k, now, count=N, fp32_scan=True)
+    assert torch.equal(r0, r2) and torch.equal(s0, s2)
+    assert bool((r2[:150, 0] == pick.to(torch.int32)).all())
+    sub = torch.cat([torch.arange(0, 6), torch.arange(294, 300)])
+    ri, rs = O.knn_exact_batch(host["bank"], host["meta"][:, 0], host["meta"][:, 1], q[sub].cpu(), k, now)
+    exact, n, ok = topk_equivalent(r2[sub], s2[sub], ri, rs)
+    print(f"\n[1M x 768 exact recall] index-exact queries vs oracle: {exact}/{n}")
+    assert ok and exact >= n - 1
+    sc = s2.cpu()
+    assert bool((sc[:, :-1] >= sc[:, 1:]).all()) and bool((r2 >= 0).all()) and bool((r2 < N).all())
+
+
+def test_1m_centroid_index_paths_vs_oracle(bank_1m, dev):
+    """Centroid-index recall at 1M x 768: inverted lists on the two-stage scan (the product's path) ==
+    fp32 inverted lists == masked two-stage scan == masked fp32 scan, bit for bit on 300 queries; the
+    oracle's candidate path on 8 of them (queries whose 8th / 9th nearest centroids are an fp32
+    near-tie are compared against the masked fp32 scan only: the probe set itself is ambiguous)."""
+    from aura_snn_rag_amd import ops
+    hf, q, pick, now, host = bank_1m
+    N, k = hf.memory_count, 32
+    s_p, r_p = hf.recall_batch(q, k=k, now=now)                                  # product: lists on the two-stage scan
+    assert hf._ivf is not None and hf._ivf.valid
+    s_m, r_m = ops.knn_search(hf.memory_features, hf._inv_norm, hf.memory_metadata, q, k, now, count=N,
+                              centroids=hf.centroids, nprobe=8, fp32_scan=True)
+    assert torch.equal(r_p, r_m) and torch.equal(s_p, s_m)
+    shadow = hf._ensure_shadow()
+    s_t, r_t = ops.knn_search(hf.memory_features, hf._inv_norm, hf.memory_metadata, q, k, now, count=N,
+                              centroids=hf.centroids, nprobe=8, shadow=shadow, rho=hf._rho)
+    assert torch.equal(r_t, r_m) and torch.equal(s_t, s_m)
+    list_rows, list_off, list_len, longest = hf._ensure_lists()
+    cap = ops.ivf_capacity(longest, k)
+    if cap is not None:
+        s_l, r_l, ovf = ops.knn_search_ivf(hf.memory_features, hf._inv_norm, hf.memory_metadata, q, k, now, N,
+                                           hf.centroids, 8, list_rows, list_off, list_len, cap)
+        assert int(ovf.item()) == 0 and torch.equal(r_l, r_m) and torch.equal(s_l, s_m)
+    ob = O.OracleBank(1, 768)
+    ob.M = N; ob.features = host["bank"]; ob.metadata = host["meta"]; ob.centroids = host["cent"]
+    ob.index_ready = True; ob.count = N
+    sub = [0, 1, 2, 3, 296, 297, 298, 299]
+    exact = ties = 0
+    for j in sub:
+        qq = q[j].cpu()
+        d = torch.sort(torch.norm(ob.centroids - qq, dim=1)).values
+        if float(d[8] - d[7]) <= 2e-6 * float(d[7]):
+            ties += 1
+            continue
+        rows, sc = ob.recall(qq, k, now)
+        e, n, ok = topk_equivalent(r_p[j:j + 1], s_p[j:j + 1], rows.unsqueeze(0), sc.unsqueeze(0))
+        assert ok, f"query {j}"
+        exact += e
+    print(f"\n[1M x 768 centroid-index recall] index-exact queries vs oracle: {exact}/{len(sub) - ties} "
+          f"({ties} probe near-ties skipped)")
+    assert exact >= len(sub) - ties - 1
+
+
+def test_config4_shard_shape_vs_oracle(dev):
+    """One rank's share of BASELINE config 4: 125 000 x 768 rows, the 8 x 256 = 2048 all-gathered queries,
+    top-32, rows reported with idx_base = first global row of the shard."""
+    from aura_snn_rag_amd import ops
+    N, D, nq, k, base = 125_000, 768, 2048, 32, 3 * 125_000
+    g = torch.Generator().manual_seed(44)
+    bank = torch.randn(N, D, generator=g)
+    meta = torch.zeros(N, 4); meta[:, 0] = 0.5 + 0.5 * torch.rand(N, generator=g); meta[:, 1] = 1.7e9; meta[:, 2] = -1
+    pick = torch.randint(0, N, (nq // 2,), generator=g)
+    q = torch.cat([bank[pick] + 0.05 * torch.randn(nq // 2, D, generator=g), torch.randn(nq - nq // 2, D, generator=g)])
+    b = bank.to(dev).contiguous(); m = meta.to(dev).contiguous(); qd = q.to(dev).contiguous()
+    inv = torch.empty(N, device=dev); ops.bank_row_norms(b, inv, 0, N)
+    shadow, rho = ops.make_shadow(b, inv)
+    s1, i1 = ops.knn_search(b, inv, m, qd, k, 1.7e9, idx_base=base, shadow=shadow, rho=rho)
+    s0, i0 = ops.knn_search(b, inv, m, qd, k, 1.7e9, idx_base=base, fp32_scan=True)
+    assert torch.equal(i0, i1) and torch.equal(s0, s1)
+    assert bool((i1 >= base).all()) and bool((i1 < base + N).all())
+    assert bool((i1[: nq // 2, 0].cpu() == (pick + base).to(torch.int32)).all())
+    sub = torch.cat([torch.arange(0, 8), torch.arange(nq - 8, nq)])
+    ri, rs = O.knn_exact_batch(bank, meta[:, 0], meta[:, 1], q[sub], k, 1.7e9)
+    exact, n, ok = topk_equivalent(i1[sub] - base, s1[sub], ri, rs)
+    print(f"\n[config-4 shard 125000 x 768, 2048 queries, idx_base {base}] index-exact queries vs oracle: {exact}/{n}")
+    assert ok and exact >= n - 1
