@@ -24,6 +24,7 @@ DTYPE_F32, DTYPE_BF16 = 0, 1
 GIF_TIME_INVARIANT, GIF_MEAN_OUT = 1, 2
 KNN_FORCE_DENSE = 1
 KNN_FP32_SCAN = 2
+KNN_FLAG_NO_CANDIDATES = 64   # bit of the overflow flag: a query without any candidate row (not an overflow)
 
 # name -> (restype, argtypes); mirrors include/aura_hip.h one to one
 P, I64, I32, F, I = c_void_p, c_int64, c_int32, c_float, c_int

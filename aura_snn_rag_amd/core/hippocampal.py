@@ -580,13 +580,12 @@ class HippocampalFormation(nn.Module):
                                                         self._rho, ivf.sorted_rows, ivf.pad_off, ivf.list_len,
                                                         n_sorted=ivf.n_sorted)
         if check_overflow and scores is not None:
-            # ONE host read for both conditions: overflow of the two-stage lists, queries without candidates
-            empty = rows[:, 0] < 0
-            flags = torch.stack([(ovf if ovf is not None else empty.new_zeros(1, dtype=torch.int32))[0] != 0,
-                                 empty.any()]).tolist()
-            if flags[0]:
+            # ONE host read for both conditions: the library's flag carries the overflow bits of the
+            # two-stage lists and the "a query has no candidate at all" bit
+            f = int(ovf.item())
+            if f & ~ops.KNN_FLAG_NO_CANDIDATES:
                 scores = rows = None                  # candidate lists too long: the fp32 paths below
-            elif not flags[1] or not fallback_empty:
+            elif not (f & ops.KNN_FLAG_NO_CANDIDATES) or not fallback_empty:
                 return scores, rows
         if scores is None and q_loc is None and full_index:
             # fp32 inverted lists: every probed list is streamed once per batch

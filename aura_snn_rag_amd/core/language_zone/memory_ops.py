@@ -17,6 +17,7 @@ import uuid
 from typing import Tuple
 
 import torch
+import torch.nn as nn
 import torch.nn.functional as F
 
 
@@ -55,6 +56,67 @@ def inject_concat(hidden_states, memory_features, memory_scores):
     w = F.softmax(memory_scores, dim=-1).unsqueeze(-1)
     ctx = (memory_features * w).sum(dim=1, keepdim=True).expand(-1, hidden_states.shape[1], -1)
     return hidden_states + 0.1 * ctx
+
+
+def inject_gate(hidden_states, memory_features, memory_scores, memory_proj, memory_gate):
+    """``memory_injection == "gate"`` (``:186-198``): the score-weighted memory context, projected, enters
+    through a sigmoid gate computed from [hidden, context]."""
+    w = F.softmax(memory_scores, dim=-1).unsqueeze(-1)
+    ctx = (memory_features * w).sum(dim=1, keepdim=True).expand(-1, hidden_states.shape[1], -1)
+    ctx = memory_proj(ctx)
+    gate = memory_gate(torch.cat([hidden_states, ctx], dim=-1))
+    return hidden_states + gate * ctx
+
+
+def inject_cross_attention(hidden_states, memory_features, memory_norm, memory_attention, dropout):
+    """``memory_injection == "cross_attention"`` (``:171-179``): the normed hidden states attend to the
+    k retrieved rows."""
+    attn_out, _ = memory_attention(query=memory_norm(hidden_states), key=memory_features, value=memory_features)
+    return hidden_states + dropout(attn_out)
+
+
+class MemoryInjection(nn.Module):
+    """The injection half of ``MemoryAugmentedLayer`` (``memory_augmented_layer.py:47-60,155-203``) as
+    a module of its own, with the reference's submodule names (``memory_norm``, ``memory_attention``,
+    ``memory_gate``, ``memory_proj``, ``query_proj``) so that a layer checkpoint's keys load with
+    ``strict=False``.  ``forward(hidden_states)`` = batched recall + row gather on the HIP bank
+    (``retrieve_memories``) followed by the configured injection."""
+
+    def __init__(self, hippocampus, embedding_dim: int, num_heads: int = 8, dropout: float = 0.1,
+                 memory_injection: str = "cross_attention", num_retrieved: int = 5):
+        super().__init__()
+        if memory_injection not in ("cross_attention", "concat", "gate"):
+            raise ValueError("memory_injection must be 'cross_attention', 'concat' or 'gate'")
+        self.hippocampus = hippocampus
+        self.memory_injection = memory_injection
+        self.num_retrieved = num_retrieved
+        if memory_injection == "cross_attention":
+            self.memory_norm = nn.LayerNorm(embedding_dim)
+            self.memory_attention = nn.MultiheadAttention(embed_dim=embedding_dim, num_heads=num_heads,
+                                                          dropout=dropout, batch_first=True)
+        elif memory_injection == "gate":
+            self.memory_gate = nn.Sequential(nn.Linear(embedding_dim * 2, embedding_dim), nn.Sigmoid())
+            self.memory_proj = nn.Linear(embedding_dim, embedding_dim)
+        self.dropout = nn.Dropout(dropout)
+        self.query_proj = nn.Linear(embedding_dim, embedding_dim)
+
+    def retrieve_memories(self, hidden_states: torch.Tensor, k: int = 5):
+        query = self.query_proj(hidden_states.mean(dim=1))
+        return retrieve_memories(self.hippocampus, query, k=k, dtype=hidden_states.dtype)
+
+    def inject_memories(self, hidden_states, memory_features, memory_scores):
+        if self.memory_injection == "cross_attention":
+            return inject_cross_attention(hidden_states, memory_features, self.memory_norm, self.memory_attention,
+                                          self.dropout)
+        if self.memory_injection == "concat":
+            return inject_concat(hidden_states, memory_features, memory_scores)
+        return inject_gate(hidden_states, memory_features, memory_scores, self.memory_proj, self.memory_gate)
+
+    def forward(self, hidden_states: torch.Tensor, use_memory: bool = True) -> torch.Tensor:
+        if use_memory and self.hippocampus is not None and self.hippocampus.memory_count > 0:
+            mf, ms = self.retrieve_memories(hidden_states, k=self.num_retrieved)
+            hidden_states = self.inject_memories(hidden_states, mf, ms)
+        return hidden_states
 
 
 class BatchedMemoryMixin:

@@ -93,27 +93,44 @@ __global__ __launch_bounds__(256) void row_inv_norm_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------------------------------
-// One-shot write without centroid maintenance: independent rows, one wave per row.
+// One-shot writes.  Both kernels compute 1/||row|| with row_inv_norm_kernel's arithmetic (same
+// per-lane fmaf chain, same butterfly), so a bank's cached norms do not depend on whether they were
+// produced by a write or recomputed after a state_dict load: recall is bit-identical either way.
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_row_sumsq(const float* __restrict__ p, int64_t D, int lane, bool vec4) {
+    float s = 0.0f;
+    if (vec4) {
+        for (int64_t i = lane * 4; i < D; i += 256) {
+            const float4 v = *reinterpret_cast<const float4*>(p + i);
+            s = fmaf(v.x, v.x, s); s = fmaf(v.y, v.y, s); s = fmaf(v.z, v.z, s); s = fmaf(v.w, v.w, s);
+        }
+    } else {
+        for (int64_t i = lane; i < D; i += 64) s = fmaf(p[i], p[i], s);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    return s;
+}
+
+// Without centroid maintenance: independent rows, one wave per row.
 __global__ __launch_bounds__(256) void bank_write_kernel(float* bank, float* loc, float* meta,
                                                          float* inv_norm, const float* feats,
                                                          const int64_t* slots, const float* cur_loc,
                                                          int sdims, float now, float cid,
-                                                         int64_t n, int64_t D) {
+                                                         int64_t n, int64_t D, int vec4) {
     const int lane = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= n) return;
     const int64_t slot = slots[i];
     const float* src = feats + i * D;
     float* dst = bank + slot * D;
-    float s = 0.0f;
-    for (int64_t c = lane; c < D; c += 64) {
-        float v = src[c];
-        dst[c] = v;
-        s = fmaf(v, v, s);
+    if (vec4) {
+        for (int64_t c = lane * 4; c < D; c += 256)
+            *reinterpret_cast<float4*>(dst + c) = *reinterpret_cast<const float4*>(src + c);
+    } else {
+        for (int64_t c = lane; c < D; c += 64) dst[c] = src[c];
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    const float s = wave_row_sumsq(src, D, lane, vec4 != 0);
     if (lane == 0) {
         inv_norm[slot] = 1.0f / fmaxf(sqrtf(s), 1e-12f);
         float4 m = make_float4(1.0f, now, cid, 0.0f);
@@ -123,65 +140,103 @@ __global__ __launch_bounds__(256) void bank_write_kernel(float* bank, float* loc
 }
 
 // ------------------------------------------------------------------------------------------
-// One-shot write WITH the online centroid update of hippocampal.py:218-230.  The update is
-// order dependent (row i sees the centroids left by rows < i), so one workgroup walks the rows
-// in order; each row's 256 x D distance scan is spread over the 1024 threads (4 per centroid).
+// One-shot write WITH the online centroid update of hippocampal.py:218-230.  The update is order
+// dependent (row i sees the centroids left by rows < i), so ONE 1024-thread workgroup walks the rows in
+// order; per row: the row goes to LDS; wave w scores centroids w, w + 16, ... (a centroid = one coalesced
+// 4 D-byte read from L2 across the lanes, four centroids in flight per wave, butterfly reduction); wave 0
+// takes the first minimum (torch.argmin) and the running mean of that centroid is updated by all
+// threads.  ~1-2 us per row (the first version spread every centroid over 4 threads reading it with a
+// 16-byte stride: 38 us per row, 10 ms for a 256-row layer batch).
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void bank_write_centroid_kernel(
     float* bank, float* loc, float* meta, float* inv_norm, float* centroids, float* counts,
     int eff_k, const float* feats, const int64_t* slots, const float* cur_loc, int sdims, float now,
-    int64_t n, int64_t D) {
-    __shared__ float s_dist[1024];
+    int64_t n, int64_t D, int vec4) {
+    extern __shared__ __attribute__((aligned(16))) float s_row[];   // [D]
+    __shared__ float s_dist[256];
     __shared__ int s_best;
-    __shared__ float s_red[16];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int64_t i = 0; i < n; ++i) {
         const int64_t slot = slots[i];
         const float* src = feats + i * D;
-        // distances: thread (c, part) with 4 parts per centroid
-        const int c = tid >> 2, part = tid & 3;
-        float acc = 0.0f;
-        if (c < eff_k) {
-            const float* cp = centroids + (int64_t)c * D;
-            for (int64_t j = part; j < D; j += 4) {
-                float d = cp[j] - src[j];
-                acc = fmaf(d, d, acc);
+        for (int64_t j = tid; j < D; j += 1024) {
+            const float v = src[j];
+            s_row[j] = v;
+            bank[slot * D + j] = v;
+        }
+        if (wave == 15) {                                    // norm + metadata shell (centroid id follows)
+            const float s = wave_row_sumsq(src, D, lane, vec4 != 0);
+            if (lane == 0) inv_norm[slot] = 1.0f / fmaxf(sqrtf(s), 1e-12f);
+            if (lane < sdims) loc[slot * sdims + lane] = cur_loc[lane];
+        }
+        __syncthreads();
+        // distances ||c - x||_2: wave w -> centroids w + 16 g
+        for (int c0 = wave; c0 < eff_k; c0 += 64) {
+            float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (vec4) {
+                for (int64_t j = lane * 4; j < D; j += 256) {
+                    const float4 x = *reinterpret_cast<const float4*>(s_row + j);
+                    float4 cv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int c = c0 + 16 * u;
+                        cv[u] = c < eff_k ? *reinterpret_cast<const float4*>(centroids + (int64_t)c * D + j)
+                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        float d = cv[u].x - x.x; acc[u] = fmaf(d, d, acc[u]);
+                        d = cv[u].y - x.y; acc[u] = fmaf(d, d, acc[u]);
+                        d = cv[u].z - x.z; acc[u] = fmaf(d, d, acc[u]);
+                        d = cv[u].w - x.w; acc[u] = fmaf(d, d, acc[u]);
+                    }
+                }
+            } else {
+                for (int64_t j = lane; j < D; j += 64) {
+                    const float x = s_row[j];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int c = c0 + 16 * u;
+                        const float d = (c < eff_k ? centroids[(int64_t)c * D + j] : 0.0f) - x;
+                        acc[u] = fmaf(d, d, acc[u]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) acc[u] += __shfl_xor(acc[u], off);
+                const int c = c0 + 16 * u;
+                if (lane == 0 && c < eff_k) s_dist[c] = sqrtf(acc[u]);
             }
         }
-        acc += __shfl_xor(acc, 1);
-        acc += __shfl_xor(acc, 2);
-        if (part == 0) s_dist[c] = (c < eff_k) ? sqrtf(acc) : INFINITY;
-        // copy row + norm
-        float s = 0.0f;
-        for (int64_t j = tid; j < D; j += 1024) {
-            float v = src[j];
-            bank[slot * D + j] = v;
-            s = fmaf(v, v, s);
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-        if ((tid & 63) == 0) s_red[tid >> 6] = s;
         __syncthreads();
-        if (tid == 0) {
-            float tot = 0.0f;
-            for (int w = 0; w < 16; ++w) tot += s_red[w];
-            inv_norm[slot] = 1.0f / fmaxf(sqrtf(tot), 1e-12f);
-            int best = 0;
-            float bd = s_dist[0];
-            for (int k = 1; k < eff_k && k < 256; ++k)
-                if (s_dist[k] < bd) { bd = s_dist[k]; best = k; }  // first minimum, as torch.argmin
-            s_best = best;
-            const float cnt = counts[best] + 1.0f;
-            counts[best] = cnt;
-            *reinterpret_cast<float4*>(meta + slot * 4) = make_float4(1.0f, now, (float)best, 0.0f);
+        if (wave == 0) {                                     // first minimum over c < eff_k, as torch.argmin
+            float bd = INFINITY;
+            int best = 0x7fffffff;
+            for (int c = lane; c < eff_k && c < 256; c += 64) {
+                const float d = s_dist[c];
+                if (d < bd) { bd = d; best = c; }            // ascending c per lane: keeps the lane's first minimum
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const float od = __shfl_xor(bd, off);
+                const int ob = __shfl_xor(best, off);
+                if (od < bd || (od == bd && ob < best)) { bd = od; best = ob; }
+            }
+            if (best == 0x7fffffff) best = 0;                // every distance NaN: torch.argmin's answer is moot
+            if (lane == 0) {
+                s_best = best;
+                counts[best] = counts[best] + 1.0f;
+                *reinterpret_cast<float4*>(meta + slot * 4) = make_float4(1.0f, now, (float)best, 0.0f);
+            }
         }
-        if (tid < sdims) loc[slot * sdims + tid] = cur_loc[tid];
         __syncthreads();
         const int best = s_best;
         const float eta = 1.0f / fmaxf(counts[best], 1.0f);
         const float one_m = 1.0f - eta;
         float* cp = centroids + (int64_t)best * D;
-        for (int64_t j = tid; j < D; j += 1024) cp[j] = one_m * cp[j] + eta * src[j];
+        for (int64_t j = tid; j < D; j += 1024) cp[j] = one_m * cp[j] + eta * s_row[j];
         __threadfence_block();
         __syncthreads();
     }
@@ -1774,14 +1829,20 @@ int aura_bank_write(float* bank, float* loc, float* meta, float* inv_norm, float
     if (!bank || !loc || !meta || !inv_norm || !feats || !slots || !cur_loc) return AURA_E_INVAL;
     if (reinterpret_cast<uintptr_t>(meta) & 15) return AURA_E_ALIGN;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    const int vec4 = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(feats) & 15) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(bank) & 15) == 0) &&
+                     (!centroids || (reinterpret_cast<uintptr_t>(centroids) & 15) == 0);
     if (centroids) {
         if (!centroid_counts || eff_k <= 0 || eff_k > 256) return AURA_E_INVAL;
-        hipLaunchKernelGGL(bank_write_centroid_kernel, dim3(1), dim3(1024), 0, s, bank, loc, meta,
+        const size_t lds = (size_t)D * sizeof(float);
+        if (lds > 150 * 1024) return AURA_E_INVAL;
+        if (ensure_lds_attr(reinterpret_cast<const void*>(bank_write_centroid_kernel), 150 * 1024)) return AURA_E_LAUNCH;
+        hipLaunchKernelGGL(bank_write_centroid_kernel, dim3(1), dim3(1024), lds, s, bank, loc, meta,
                            inv_norm, centroids, centroid_counts, eff_k, feats, slots, cur_loc,
-                           spatial_dims, now, n, D);
+                           spatial_dims, now, n, D, vec4);
     } else {
         hipLaunchKernelGGL(bank_write_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, bank,
-                           loc, meta, inv_norm, feats, slots, cur_loc, spatial_dims, now, -1.0f, n, D);
+                           loc, meta, inv_norm, feats, slots, cur_loc, spatial_dims, now, -1.0f, n, D, vec4);
     }
     return check_launch();
 }

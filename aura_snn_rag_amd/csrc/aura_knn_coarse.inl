@@ -1042,6 +1042,7 @@ __global__ __launch_bounds__(RF_THREADS) void coarse_refine_kernel(const RefineA
     int S = s_ns;
     if (S > RF_SURV) { ovf = true; ovf_bits |= 8; S = RF_SURV; }
     if (ovf && tid == 0 && a.overflow) atomicOr(a.overflow, ovf_bits);   // which list overflowed
+    if (S == 0 && tid == 0 && a.overflow) atomicOr(a.overflow, AURA_KNN_FLAG_NO_CANDIDATES);   // (not an overflow)
     __syncthreads();     // candidate arrays are dead from here: rsmem is reused below
 
     // ---- exact re-scoring: rounds of 8 x RF_ROWS survivors, survivor base + 8 r + w -> wave w, slot r ----

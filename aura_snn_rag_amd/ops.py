@@ -12,7 +12,7 @@ from typing import Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import check
+from ._lib import check, KNN_FLAG_NO_CANDIDATES
 
 
 class AuraDeviceError(RuntimeError):
@@ -365,7 +365,7 @@ def knn_search(bank, inv_norm, meta, queries, k: int, now: float, count: Optiona
               "aura_knn_search_ex")
 
     run(_lib.KNN_FORCE_DENSE if force_dense else (_lib.KNN_FP32_SCAN if fp32_scan else 0))
-    if check_overflow and not force_dense and int(ovf.item()) != 0:
+    if check_overflow and not force_dense and (int(ovf.item()) & ~_lib.KNN_FLAG_NO_CANDIDATES) != 0:
         run(_lib.KNN_FORCE_DENSE)
     return (out_s, out_i, ovf) if return_flag else (out_s, out_i)
 

@@ -56,9 +56,8 @@ class ShardedRecall:
                ) -> Tuple[torch.Tensor, torch.Tensor]:
         S = self.world
         nq = queries.shape[0]
-        if not dist.is_initialized():
-            s, r = self.local_search(queries, k)
-            return self.merge(s.unsqueeze(0), r.unsqueeze(0), k)
+        if not dist.is_initialized() or S == 1:
+            return self.local_search(queries, k)     # one shard: its sorted top-k is the result
         if all_gather_queries:
             allq = torch.empty(S * nq, queries.shape[1], dtype=queries.dtype, device=queries.device)
             dist.all_gather_into_tensor(allq, queries.contiguous(), group=self.group)
@@ -274,8 +273,9 @@ class ShardedHippocampus:
             pad = kk - s.shape[1]
             s = torch.cat([s, torch.full((s.shape[0], pad), float("-inf"), device=s.device)], dim=1)
             r = torch.cat([r, torch.full((r.shape[0], pad), -1, dtype=torch.int32, device=r.device)], dim=1)
-        r = torch.where(r >= 0, r + self.row_base, r)
-        s = torch.where(r >= 0, s, torch.full_like(s, float("-inf")))
+        if self.world > 1:
+            r = torch.where(r >= 0, r + self.row_base, r)
+            s = torch.where(r >= 0, s, torch.full_like(s, float("-inf")))
         return s.contiguous(), r.contiguous()
 
     def recall_batch(self, queries: torch.Tensor, k: int = 5, now: Optional[float] = None,

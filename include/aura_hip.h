@@ -134,6 +134,10 @@ int aura_knn_search(const float* bank, const float* inv_norm, const float* meta,
  * candidate row id outside [0, N) reached the re-scoring stage (an internal invariant broke; the row
  * is dropped instead of dereferenced) -- the caller must then re-run with AURA_KNN_FORCE_DENSE; may
  * be NULL). */
+/* overflow_out bit 6: some query of a two-stage call ended with NO candidate row at all (its probed
+ * centroids own no rows): its outputs are -inf / -1 and the caller applies the reference's full-scan
+ * fallback (hippocampal.py:269-270).  Not an overflow: the other queries' results are complete. */
+#define AURA_KNN_FLAG_NO_CANDIDATES 64
 #define AURA_KNN_FORCE_DENSE 1
 /* AURA_KNN_FP32_SCAN: score every row on the fp32 matrix pipe.  Without it, large banks
  * (>= 8192 rows, D <= 768, D % 4 == 0, no location term / centroid mask, k <= 256) are first

@@ -33,7 +33,7 @@ def sweep(cases=30, seed=0, dev=None, verbose=True):
         st = ops.build_ivf2(bank, inv, meta[:, 2], slack=slack)
         s1, r1, o1 = ops.knn_search_ivf2(bank, inv, meta, q, k, now, cent, 8, st["sorted_bf16"], st["rho"],
                                          st["sorted_rows"], st["pad_off"], st["list_len"], n_sorted=st["n_sorted"])
-        flag = int(o1.item())
+        flag = int(o1.item()) & ~ops.KNN_FLAG_NO_CANDIDATES
         s0, r0 = ops.knn_search(bank, inv, meta, q, k, now, centroids=cent, nprobe=8, fp32_scan=True)
         # third path: the masked two-stage scan over the (unsorted) bf16 shadow
         shadow, rho = ops.make_shadow(bank, inv)

@@ -287,3 +287,49 @@ def test_hip_prosody_golden(dev):
     assert torch.equal(s.cpu(), d["spikes_cont"]) and torch.equal(v.cpu(), d["v_cont"]) and torch.equal(th.cpu(), d["theta_cont"])
     s, v, th = run(v0, t0, None)
     assert torch.equal(s.cpu(), d["spikes_nogain"]) and torch.equal(v.cpu(), d["v_nogain"]) and torch.equal(th.cpu(), d["theta_nogain"])
+
+
+def _rate_code_bank(dev_name):
+    from aura_snn_rag_amd.core import hippocampal as H
+    gold = torch.load(os.path.join(G, "rate_codes.pt"))
+    torch.manual_seed(gold["seed"])
+    hf = H.HippocampalFormation(device=dev_name, **gold["ctor"])
+    return H, hf, gold
+
+
+def test_rate_codes_match_reference_cpu(monkeypatch):
+    """place / grid / time-cell rate codes (hippocampal.py:120-193) against vectors the
+    reference produced: the seeded cell parameters and the codes are bit-equal on the CPU."""
+    H, hf, gold = _rate_code_bank("cpu")
+    for k_, v in gold["buffers"].items():
+        assert torch.equal(getattr(hf, k_).cpu(), v), k_
+    clock = [1.7e9]
+    monkeypatch.setattr(H.time, "time", lambda: clock[0])
+    hf.last_event_time = 1.7e9
+    for c in gold["cases"]:
+        hf.update_spatial_state(c["location"])
+        sp = hf.get_spatial_context()
+        clock[0] = 1.7e9 + c["elapsed"]
+        tc = hf.get_temporal_context()
+        assert torch.equal(sp["place_cells"], c["place"]) and torch.equal(sp["grid_cells"], c["grid"])
+        assert torch.equal(tc["time_cells"], c["time"]) and tc["elapsed"] == c["elapsed"]
+
+
+@pytest.mark.gpu
+def test_rate_codes_match_reference_gpu(dev, monkeypatch):
+    """The same codes computed on the device (plain torch ops there): device exp / cos differ
+    from the host's by ulps, so 1e-5 relative."""
+    H, hf, gold = _rate_code_bank("cuda")
+    for k_, v in gold["buffers"].items():
+        getattr(hf, k_).copy_(v)                  # the device RNG draws other cells than the reference's CPU RNG
+    clock = [1.7e9]
+    monkeypatch.setattr(H.time, "time", lambda: clock[0])
+    hf.last_event_time = 1.7e9
+    for c in gold["cases"]:
+        hf.update_spatial_state(c["location"].to(dev))
+        sp = hf.get_spatial_context()
+        clock[0] = 1.7e9 + c["elapsed"]
+        tc = hf.get_temporal_context()
+        assert torch.allclose(sp["place_cells"].cpu(), c["place"], rtol=1e-5, atol=1e-5)
+        assert torch.allclose(sp["grid_cells"].cpu(), c["grid"], rtol=1e-5, atol=2e-5)
+        assert torch.allclose(tc["time_cells"].cpu(), c["time"], rtol=1e-5, atol=1e-6)

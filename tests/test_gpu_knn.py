@@ -543,7 +543,7 @@ def test_inverted_lists_two_stage(dev, N, D, nq, k, ncent):
     assert torch.equal(st["pos_of_row"][srows[listed].long()].long(), listed)
     s1, r1, o1 = ops.knn_search_ivf2(bank, inv, meta, q, k, NOW, cent, 8, st["sorted_bf16"], st["rho"], srows, pad_off,
                                      st["list_len"], n_sorted=st["n_sorted"])
-    flag = int(o1.item())                 # read before the next search resets the shared flag
+    flag = int(o1.item()) & ~ops.KNN_FLAG_NO_CANDIDATES   # read before the next search resets the shared flag
     s0, r0 = ops.knn_search(bank, inv, meta, q, k, NOW, centroids=cent, nprobe=8, fp32_scan=True)
     if flag != 0:
         # k = 64 over 40 real centroids: a query that probes ONE real list (the rest of its 8 nearest

@@ -179,3 +179,21 @@ def test_surrogate_gradients_and_prosody_bit_exact():
             os_, ov, ot = O.prosody_gif_run(pg.linear(x), torch.zeros(3, 20), torch.full((3, 20), pg.threshold),
                                             gn, pg.decay, 8, 0.02, pg.threshold, 0.4)
             assert torch.equal(rs, os_) and torch.equal(rv, ov) and torch.equal(rt, ot)
+
+
+@pytest.mark.parametrize("mode", ["cross_attention", "concat", "gate"])
+def test_memory_injection_modes_match_reference_layer(mode):
+    """inject_memories of the reference layer (memory_augmented_layer.py:155-203), all three modes, against
+    aura_snn_rag_amd's MemoryInjection with the layer's own weights loaded: bit-equal on CPU."""
+    import types
+    M = L.load("src.core.language_zone.memory_augmented_layer")
+    from aura_snn_rag_amd.core.language_zone.memory_ops import MemoryInjection
+    cfg = types.SimpleNamespace(embedding_dim=32, num_heads=4, dropout=0.0, intermediate_size=64)
+    torch.manual_seed(0)
+    layer = M.MemoryAugmentedLayer(cfg, hippocampus=None, use_snn_ffn=False, memory_injection=mode, num_retrieved=5).eval()
+    mine = MemoryInjection(None, 32, num_heads=4, dropout=0.0, memory_injection=mode).eval()
+    missing, unexpected = mine.load_state_dict(layer.state_dict(), strict=False)
+    assert not missing, f"keys the reference layer does not provide: {missing}"
+    h, mf, ms = torch.randn(3, 7, 32), torch.randn(3, 5, 32), torch.randn(3, 5)
+    with torch.no_grad():
+        assert torch.equal(layer.inject_memories(h, mf, ms), mine.inject_memories(h, mf, ms))
