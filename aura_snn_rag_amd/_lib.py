@@ -24,6 +24,7 @@ DTYPE_F32, DTYPE_BF16 = 0, 1
 GIF_TIME_INVARIANT, GIF_MEAN_OUT = 1, 2
 KNN_FORCE_DENSE = 1
 KNN_FP32_SCAN = 2
+KNN_FLAG_LISTS_STALE = 128     # bit of the overflow flag: the inverted lists dropped a row (re-pack and repeat)
 KNN_FLAG_NO_CANDIDATES = 64   # bit of the overflow flag: a query without any candidate row (not an overflow)
 
 # name -> (restype, argtypes); mirrors include/aura_hip.h one to one
@@ -62,7 +63,7 @@ SIGNATURES = {
     "aura_knn_ivf2_workspace_bytes": (I64, [I64, I64, I]),
     "aura_bank_shadow_sorted": (I, [P, P, P, P, P, P, I64, I64, P]),
     "aura_ivf2_append": (I, [P, P, P, P, I64, I64, P, P, P, P, P, P, P, P]),
-    "aura_knn_search_ivf2": (I, [P, P, P, P, P, P, P, P, I64, I64, P, F, I64, I64, I, P, I, I32, P, P, P, I64, P, P]),
+    "aura_knn_search_ivf2": (I, [P, P, P, P, P, P, P, P, P, I64, I64, P, F, I64, I64, I, P, I, I32, P, P, P, I64, P, P]),
     "aura_profile_begin": (I, [I]),
     "aura_profile_end": (I, [P, I]),
     "aura_profile_last_scan": (I, [P, P]),

@@ -271,6 +271,7 @@ class HippocampalFormation(nn.Module):
             ops.ivf2_layout(order, seg_off, slack, st.sorted_rows, st.pad_off, st.list_len)
             st.n_sorted = min(st.n_alloc, ops.ivf2_alloc_rows(n, slack))
             st.pos_of_row.fill_(-1)
+            st.flag.zero_()
             ops.bank_shadow_sorted(self.memory_features, self._inv_norm, st.sorted_rows, st.sorted_bf16, rho,
                                    st.pos_of_row, st.n_sorted)
             st.appended = 0
@@ -282,8 +283,12 @@ class HippocampalFormation(nn.Module):
         st = self._ivf
         if st is None or not st.valid:
             return
-        if st.appended + n_rows > st.slack or self._rho is None:
-            st.valid = False                       # slack used up: re-pack at the next recall
+        # Rows spread over the 256 lists, so a list's slack lasts far longer than `slack` appended rows;
+        # the append kernel flags a list that does overflow (the row is then missing from the lists) and
+        # the next recall sees that flag in the read it does anyway (recall_batch).  Holes (overwritten
+        # rows) are scanned like padding: re-pack once they are worth it.
+        if self._rho is None or st.appended + n_rows > max(st.slack, self.memory_count // 8):
+            st.valid = False
             return
         ops.ivf2_append(self.memory_features, self._inv_norm, self.memory_metadata, uniq_slots, st.sorted_bf16,
                         st.sorted_rows, st.pad_off, st.list_len, st.pos_of_row, self._rho, st.flag)
@@ -572,17 +577,24 @@ class HippocampalFormation(nn.Module):
                                                check_overflow=False, return_flag=True)
         elif q_loc is None and full_index and kk <= 256:
             ivf = self._ensure_ivf()
+            if ivf is not None and not check_overflow and ivf.appended > ivf.slack:
+                ivf.valid = False                     # nobody will read the lists' flag: stay within the proven slack
+                ivf = self._ensure_ivf()
             if ivf is not None:
                 # large banks / large batches: inverted lists on the two-stage scan (every probed list is
                 # streamed once per 2048 queries from the list-sorted bf16 shadow); same rows and score bits
                 scores, rows, ovf = ops.knn_search_ivf2(self.memory_features, self._inv_norm, self.memory_metadata,
                                                         q, kk, now, self.centroids, nprobe, ivf.sorted_bf16,
                                                         self._rho, ivf.sorted_rows, ivf.pad_off, ivf.list_len,
-                                                        n_sorted=ivf.n_sorted)
+                                                        n_sorted=ivf.n_sorted, lists_flag=ivf.flag)
         if check_overflow and scores is not None:
             # ONE host read for both conditions: the library's flag carries the overflow bits of the
             # two-stage lists and the "a query has no candidate at all" bit
             f = int(ovf.item())
+            if f & ops.KNN_FLAG_LISTS_STALE:          # a write outgrew a list's slack: re-pack, then once more
+                self._ivf.valid = False
+                return self.recall_batch(queries, k=k, locations=locations, now=now, use_candidates=use_candidates,
+                                         check_overflow=check_overflow, fallback_empty=fallback_empty)
             if f & ~ops.KNN_FLAG_NO_CANDIDATES:
                 scores = rows = None                  # candidate lists too long: the fp32 paths below
             elif not (f & ops.KNN_FLAG_NO_CANDIDATES) or not fallback_empty:
@@ -677,9 +689,7 @@ class HippocampalFormation(nn.Module):
         self.decay_memories(decay_rate=rate)
 
     def rebuild_centroids(self, perm: Optional[torch.Tensor] = None) -> None:
-        """One Lloyd iteration from a random sample of rows (reference ``:345-377``).  The
-        ``randperm`` is drawn from torch's global CPU generator exactly as the reference does on a
-        CPU device, so a seeded run reproduces its sample.
+        """One Lloyd iteration from a random sample of rows (reference ``:345-377``).
 
         assign (fp32 matrix cores) -> rows grouped by cluster (device sort) -> means as a segmented
         reduction (the bank is read once) -> second assign -> counts + metadata; the second grouping
@@ -689,7 +699,11 @@ class HippocampalFormation(nn.Module):
         n = self.memory_count
         k = min(self.centroids_k, n)
         if perm is None:
-            perm = torch.randperm(n)
+            # The reference draws randperm(n, device=self.device) (:354).  Up to 2^18 rows the draw comes from
+            # torch's CPU generator, so a seeded run reproduces the reference's CPU run (the golden vectors);
+            # a full CPU permutation of a 1M-row bank costs ~10 ms per rebuild, so larger banks draw from the
+            # device generator, as the reference itself does on a GPU.
+            perm = torch.randperm(n) if n <= (1 << 18) else torch.randperm(n, device=self.device)
         init = ops.bank_gather(self.memory_features, perm[:k].to(device=self.device, dtype=torch.int32))
         cent = torch.zeros_like(self.centroids)
         cent[:k] = init

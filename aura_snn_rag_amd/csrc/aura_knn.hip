@@ -2074,7 +2074,8 @@ int64_t aura_knn_ivf2_workspace_bytes(int64_t n_sorted, int64_t nq, int k) {
 
 int aura_knn_search_ivf2(const float* bank, const float* inv_norm, const float* meta,
                          const uint16_t* sorted_bf16, const float* rho, const int32_t* sorted_rows, const int32_t* pad_off,
-                         const int32_t* list_len, int64_t n_sorted, int64_t N, const float* queries, float now,
+                         const int32_t* list_len, const int32_t* lists_flag, int64_t n_sorted, int64_t N,
+                         const float* queries, float now,
                          int64_t D, int64_t nq, int k,
                          const float* centroids, int nprobe, int32_t idx_base, float* out_scores,
                          int32_t* out_idx, void* workspace, int64_t workspace_bytes,
@@ -2126,7 +2127,7 @@ int aura_knn_search_ivf2(const float* bank, const float* inv_norm, const float* 
         const int qblocks = IVF2_MAXBLK * 256 / 4;
         hipLaunchKernelGGL(ivf2_prep_kernel, dim3((unsigned)(qblocks + (n_sorted + 255) / 256)), dim3(256), 0, s,
                            qptr, (int64_t)nqb, D, KS, w.lq_cnt, w.lq_list, w.blk_off, w.blk_list, w.nblk, w.qhat,
-                           w.inv_q, w.slotq, w.qslot, w.thr, qb0 == 0 ? overflow_out : nullptr, w.eq_slot, w.eq_q,
+                           w.inv_q, w.slotq, w.qslot, w.thr, qb0 == 0 ? overflow_out : nullptr, lists_flag, w.eq_slot, w.eq_q,
                            qblocks, meta, rho, sorted_rows, n_sorted, now, e_fix, w.rowc);
         if ((rc = check_launch())) return rc;
         stage("prep");

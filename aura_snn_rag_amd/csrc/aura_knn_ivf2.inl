@@ -87,6 +87,7 @@ __global__ __launch_bounds__(256) void ivf2_prep_kernel(const float* __restrict_
                                                         uint16_t* __restrict__ qhat, float* __restrict__ inv,
                                                         int32_t* __restrict__ slotq, int32_t* __restrict__ qslot,
                                                         uint32_t* __restrict__ thr, int32_t* overflow,
+                                                        const int32_t* __restrict__ lists_flag,
                                                         float* __restrict__ eq_slot, float* __restrict__ eq_q,
                                                         int qblocks, const float* __restrict__ meta,
                                                         const float* __restrict__ rho,
@@ -107,7 +108,9 @@ __global__ __launch_bounds__(256) void ivf2_prep_kernel(const float* __restrict_
     }
     const int lane = threadIdx.x & 63;
     const int64_t vs = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);     // virtual slot = B * 256 + slot
-    if (overflow && blockIdx.x == 0 && threadIdx.x == 0) *overflow = 0;
+    // reset of the call's flag; bit 7: aura_ivf2_append dropped a row because a list had no slack left
+    if (overflow && blockIdx.x == 0 && threadIdx.x == 0)
+        *overflow = (lists_flag && *lists_flag) ? AURA_KNN_FLAG_LISTS_STALE : 0;
     const int B = (int)(vs >> 8);
     if (B >= nblk[0]) return;
     const int list = blk_list[B];

@@ -12,7 +12,7 @@ from typing import Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import check, KNN_FLAG_NO_CANDIDATES
+from ._lib import check, KNN_FLAG_LISTS_STALE, KNN_FLAG_NO_CANDIDATES
 
 
 class AuraDeviceError(RuntimeError):
@@ -514,12 +514,13 @@ def ivf2_append(bank, inv_norm, meta, slots, sorted_shadow, sorted_rows, pad_off
 
 def knn_search_ivf2(bank, inv_norm, meta, queries, k: int, now: float, centroids, nprobe: int,
                     sorted_shadow, rho, sorted_rows, pad_off, list_len, idx_base: int = 0,
-                    n_sorted: Optional[int] = None
+                    n_sorted: Optional[int] = None, lists_flag=None
                     ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """Inverted-list recall through the two-stage scan: (scores [nq, k], idx [nq, k], overflow flag [1]).
     Same results as ``knn_search_ivf``; layout arrays from ``ivf2_layout`` + ``bank_shadow_sorted``
     (kept current by ``ivf2_append``).  ``n_sorted``: sorted rows in use (a multiple of 16 that covers
-    pad_off[256]; default: all of ``sorted_rows``)."""
+    pad_off[256]; default: all of ``sorted_rows``).  ``lists_flag``: ``ivf2_append``'s flag; if it is
+    set the returned overflow flag carries ``KNN_FLAG_LISTS_STALE``."""
     _need(bank, "bank", torch.float32); _need(inv_norm, "inv_norm", torch.float32)
     _need(meta, "meta", torch.float32); _need(queries, "queries", torch.float32)
     _need(centroids, "centroids", torch.float32); _need(sorted_shadow, "sorted_shadow", torch.bfloat16)
@@ -548,8 +549,10 @@ def knn_search_ivf2(bank, inv_norm, meta, queries, k: int, now: float, centroids
     nbytes = L.aura_knn_ivf2_workspace_bytes(ns, nq, k)
     ws = _workspace(dev, nbytes)
     base = (ws.data_ptr() + 255) // 256 * 256
+    if lists_flag is not None:
+        _need(lists_flag, "lists_flag", torch.int32)
     check(L.aura_knn_search_ivf2(_p(bank), _p(inv_norm), _p(meta), _p(sorted_shadow), _p(rho), _p(sorted_rows),
-                                 _p(pad_off), _p(list_len), ns, M, _p(queries), now, D, nq, k,
+                                 _p(pad_off), _p(list_len), _p(lists_flag), ns, M, _p(queries), now, D, nq, k,
                                  _p(centroids), nprobe, idx_base, _p(out_s), _p(out_i), base, nbytes,
                                  _p(ovf), _stream()), "aura_knn_search_ivf2")
     return out_s, out_i, ovf

@@ -138,6 +138,9 @@ int aura_knn_search(const float* bank, const float* inv_norm, const float* meta,
  * centroids own no rows): its outputs are -inf / -1 and the caller applies the reference's full-scan
  * fallback (hippocampal.py:269-270).  Not an overflow: the other queries' results are complete. */
 #define AURA_KNN_FLAG_NO_CANDIDATES 64
+/* overflow_out bit 7 (aura_knn_search_ivf2): the caller's lists_flag was set -- aura_ivf2_append dropped
+ * a row because its list had no free entry left: the lists must be re-packed and the call repeated. */
+#define AURA_KNN_FLAG_LISTS_STALE 128
 #define AURA_KNN_FORCE_DENSE 1
 /* AURA_KNN_FP32_SCAN: score every row on the fp32 matrix pipe.  Without it, large banks
  * (>= 8192 rows, D <= 768, D % 4 == 0, no location term / centroid mask, k <= 256) are first
@@ -252,8 +255,9 @@ int aura_knn_search_shadow(const float* bank, const uint16_t* bank_bf16, const f
  * receives the reverse map bank row -> sorted row for aura_ivf2_append).
  * aura_ivf2_append: after a write of n DISTINCT bank rows `slots` (device int64) whose centroid ids
  * are in meta[.][2]: the row's previous entry becomes a hole (-1), the row is appended to its list
- * (bf16 row converted, rho refreshed, pos_of_row updated).  The caller guarantees that no list
- * outgrows its slack (it re-packs after at most `slack` appended rows); *flag |= 1 otherwise.
+ * (bf16 row converted, rho refreshed, pos_of_row updated).  A row whose list has no free entry left is
+ * dropped from the lists and *flag |= 1: pass that flag to aura_knn_search_ivf2 as lists_flag (it is
+ * reported as AURA_KNN_FLAG_LISTS_STALE) or re-pack after at most `slack` appended rows.
  * aura_knn_search_ivf2: each probed list is streamed once per batch of up to 2048 queries against
  * the queries that probe it; results (rows, score bits) equal aura_knn_search_ivf's.  N = rows of
  * the bank (every sorted_rows entry is < N).  D % 8 == 0, D <= 768, k <= 256, nprobe <= 8;
@@ -267,8 +271,8 @@ int aura_ivf2_append(const float* bank, const float* inv_norm, const float* meta
                      int32_t* list_len, int32_t* pos_of_row, float* rho, int32_t* flag, void* stream);
 int aura_knn_search_ivf2(const float* bank, const float* inv_norm, const float* meta,
                          const uint16_t* sorted_bf16, const float* rho, const int32_t* sorted_rows,
-                         const int32_t* pad_off, const int32_t* list_len, int64_t n_sorted, int64_t N,
-                         const float* queries, float now, int64_t D, int64_t nq, int k,
+                         const int32_t* pad_off, const int32_t* list_len, const int32_t* lists_flag,
+                         int64_t n_sorted, int64_t N, const float* queries, float now, int64_t D, int64_t nq, int k,
                          const float* centroids, int nprobe, int32_t idx_base, float* out_scores,
                          int32_t* out_idx, void* workspace, int64_t workspace_bytes, int32_t* overflow_out,
                          void* stream);

@@ -9,6 +9,9 @@ import torch.nn.functional as F
 from oracle import aura_oracle as O
 
 
+KNN_FLAG_NO_CANDIDATES, KNN_FLAG_LISTS_STALE = 64, 128
+
+
 class AuraDeviceError(RuntimeError):
     pass
 

@@ -208,6 +208,16 @@ def test_inverted_lists_follow_writes_incrementally(dev):
         b.rebuild_centroids(perm=torch.randperm(M, generator=torch.Generator().manual_seed(3)))
         same()
         assert len(packs) == n_packs + 1
+        # one list outgrows its slack (700 near-copies of one row, slack 512): the append kernel drops the
+        # overflowing rows and raises the lists' flag, the next recall sees it in its one flag read, re-packs
+        # and repeats -- no result ever comes from stale lists
+        burst = a.memory_features[123].cpu() + 0.01 * torch.randn(700, D, generator=g)
+        for j in range(0, 700, 100):
+            for hf in (a, b):
+                hf.create_episodic_memories([f"b{j + i}" for i in range(100)], burst[j:j + 100])
+        assert a._ivf.valid and int(a._ivf.flag.item()) == 1
+        same()
+        assert len(packs) == n_packs + 2 and int(a._ivf.flag.item()) == 0
     finally:
         ops.bank_shadow_sorted = orig
 

@@ -61,3 +61,28 @@ def test_centroid_index_biases_retrieval_and_fallback_and_decay():
     before = one.metadata[0, 0].item()
     one.decay(0.1)
     assert 0 < one.metadata[0, 0].item() < before
+
+
+def test_bf16_quotients_are_never_near_a_rounding_midpoint():
+    """The bf16 GIF kernel replaces the IEEE division by v * rcp(t) (aura_neuron.hip, GifModel::quot).  That
+    is exact iff the real quotient of two bf16 numbers is never within the approximation's error of a
+    bf16 rounding midpoint.  Exhaustive over all significand pairs (the exponents only shift): the
+    quotient is never a midpoint and stays >= 2^-17 (relative) away from every one -- 32x the error of
+    v_rcp_f32 (1 ulp) times one fp32 rounding."""
+    from fractions import Fraction
+    worst = None
+    for mv in range(128, 256):
+        for mt in range(128, 256):
+            x = Fraction(mv, mt)
+            while x >= 2:
+                x /= 2
+            while x < 1:
+                x *= 2
+            # bf16 values in [1, 2): 1 + j/128; midpoints: 1 + (2j + 1)/256
+            j = int((x - 1) * 256)                         # x lies in [1 + j/256, 1 + (j+1)/256)
+            for n in (j - 1, j, j + 1, j + 2):
+                if n % 2 == 1 and 0 < n < 512:
+                    d = abs(x - (1 + Fraction(n, 256))) / x
+                    assert d != 0, (mv, mt)
+                    worst = d if worst is None or d < worst else worst
+    assert worst >= Fraction(1, 2 ** 17), float(worst)
