@@ -34,3 +34,26 @@ def test_checker_flags_a_violation(tmp_path):
                  "\tv_add_f32 v20, v1, v2\n\ts_nop 1\n\tv_mfma_f32_16x16x32_bf16 a[0:3], v[20:23], a[4:7], a[0:3]\n")
     n, bad = chk.check(str(p))
     assert n == 2 and len(bad) == 1 and "v_cvt_pk" in bad[0][2]
+
+
+def test_checker_follows_labels_and_back_edges(tmp_path):
+    """a VALU write at the end of one basic block followed by an MFMA at the top of the next
+    (fall-through, or the back edge of a loop) must be seen, and so must a read of an MFMA result that
+    comes too early."""
+    import check_mfma_hazards as chk
+    p = tmp_path / "y.s"
+    p.write_text("coarse_scan_kernel_demo:\n"
+                 "\tv_add_f32 v12, v8, v9\n"                                   # falls through the label into the MFMA
+                 ".LBB0_1:\n"
+                 "\tv_mfma_f32_16x16x32_bf16 a[0:3], v[12:15], a[4:7], a[0:3]\n"
+                 "\ts_nop 7\n\ts_nop 4\n"
+                 "\tv_accvgpr_read_b32 v30, a0\n"                               # fine: 13 wait states behind the MFMA
+                 "\tv_mov_b32 v13, v1\n"                                        # ... and the back edge carries this write
+                 "\ts_cbranch_vccnz .LBB0_1\n"                                  #     to the MFMA at the loop head
+                 "\tv_mfma_f32_16x16x32_bf16 a[8:11], v[20:23], a[4:7], a[8:11]\n"
+                 "\ts_nop 3\n"
+                 "\tv_accvgpr_read_b32 v31, a8\n")                              # too early
+    n, bad = chk.check(str(p))
+    assert n == 2
+    kinds = sorted(b[2].split()[0] for b in bad)
+    assert kinds == ["v_add_f32", "v_mfma_f32_16x16x32_bf16", "v_mov_b32"], bad
