@@ -112,7 +112,7 @@ __device__ __forceinline__ void round_bf16_pair(float& a, float& b) {
 //    every midpoint: |mv 2^s 256 - N mt| >= 1 for odd N, mt <= 255.  Any approximation of x that is
 //    good to 2^-18 therefore rounds to the same bf16 value: v * rcp(t) (v_rcp_f32: 1 ulp) replaces
 //    the ~10-instruction IEEE division, bit for bit (the whole bf16 GIF suite, and the exhaustive
-//    significand-pair check in tests/test_oracle_known_answers.py).
+//    significand-pair proof in the CPU test suite, test_bf16_quotients_are_never_near_a_rounding_midpoint).
 //  * POW2L: for L a power of two, L * theta and its doubling are exact in bf16: no rounding.
 template <bool BF16, bool POW2L = false>
 struct GifModel {

@@ -247,6 +247,133 @@ __global__ __launch_bounds__(256) void gif_prosody_kernel(GifP p, float strength
     }
 }
 
+// Training forward of the prosody GIF: as gif_prosody_kernel, also saving the pre-clamp potential a_t and
+// the threshold theta_{t-1} of every step (everything else is recomputed in backward).
+template <int VEC>
+__global__ __launch_bounds__(256) void gif_prosody_train_fwd_kernel(GifP p, float strength,
+                                                                    const float* __restrict__ h,
+                                                                    const float* __restrict__ gains,
+                                                                    float* __restrict__ spikes, float* v_io,
+                                                                    float* th_io, float* __restrict__ save_a,
+                                                                    float* __restrict__ save_th, int64_t R,
+                                                                    int64_t T, int64_t C) {
+    const int64_t cv = C / VEC, items = R * cv;
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < items;
+         it += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = it / cv, c0 = (it - row * cv) * VEC;
+        float v[VEC], th[VEC];
+        V<VEC>::ld(v_io + row * C + c0, v);
+        V<VEC>::ld(th_io + row * C + c0, th);
+        for (int64_t t = 0; t < T; ++t) {
+            const int64_t o = (row * T + t) * C + c0;
+            float x[VEC], s[VEC], a[VEC], thp[VEC];
+            V<VEC>::ld(h + o, x);
+            const bool mod = gains != nullptr;
+            const float g = mod ? gains[row * T + t] : 1.0f;
+            const float scale = fminf(fmaxf(1.0f - strength * (g - 1.0f), 0.5f), 1.5f);
+            const float a_eff = mod ? p.alpha * g : p.alpha;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                thp[e] = th[e];
+                const float i_t = mod ? x[e] * g : x[e];
+                a[e] = v[e] * p.decay + i_t;
+                const float te = mod ? th[e] * scale : th[e];
+                const float cl = p.Lf * te * 2.0f;
+                const float b = fminf(fmaxf(a[e], -cl), cl);
+                s[e] = fminf(fmaxf(floorf(b / te), 0.0f), p.Lf);
+                v[e] = b - s[e] * te;
+                if (p.alpha > 0.0f) th[e] = th[e] + a_eff * s[e] - a_eff * (th[e] - p.thr0);
+            }
+            V<VEC>::st(spikes + o, s);
+            V<VEC>::st(save_a + o, a);
+            V<VEC>::st(save_th + o, thp);
+        }
+        V<VEC>::st(v_io + row * C + c0, v);
+        V<VEC>::st(th_io + row * C + c0, th);
+    }
+}
+
+// Backward of that loop (BPTT, reverse time).  Per step, with g = gains[row][t], scale = clamp(1 - str (g - 1),
+// 0.5, 1.5), te = thp scale, ae = alpha g:
+//   theta_t = thp + ae s - ae (thp - thr0);  v_t = b - s te;  s = surrogate(n), n = b / te;
+//   b = clamp(a, -2 L te, 2 L te);  a = v_{t-1} decay + x g.
+// Besides dL/dh and the initial-state gradients it returns dL/dgains[row][t] (summed over the channels with
+// float atomics: g_gains must be zeroed by the caller): through the input gain (x), the threshold scale
+// (-strength where the clamp is inactive) and the adaptation rate (alpha).
+template <int VEC>
+__global__ __launch_bounds__(256) void gif_prosody_bwd_kernel(GifP p, float strength,
+                                                              const float* __restrict__ save_a,
+                                                              const float* __restrict__ save_th,
+                                                              const float* __restrict__ h,
+                                                              const float* __restrict__ gains,
+                                                              const float* __restrict__ g_spikes,
+                                                              float* __restrict__ g_h, float* __restrict__ g_gains,
+                                                              float* gv_io, float* gth_io, int64_t R, int64_t T,
+                                                              int64_t C) {
+    const int64_t cv = C / VEC, items = R * cv;
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < items;
+         it += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = it / cv, c0 = (it - row * cv) * VEC;
+        float gv[VEC], gth[VEC];
+        V<VEC>::ld(gv_io + row * C + c0, gv);
+        V<VEC>::ld(gth_io + row * C + c0, gth);
+        for (int64_t t = T - 1; t >= 0; --t) {
+            const int64_t o = (row * T + t) * C + c0;
+            float a[VEC], thp[VEC], gs[VEC], gh[VEC], x[VEC];
+            V<VEC>::ld(save_a + o, a);
+            V<VEC>::ld(save_th + o, thp);
+            V<VEC>::ld(g_spikes + o, gs);
+            V<VEC>::ld(h + o, x);
+            const bool mod = gains != nullptr;
+            const float g = mod ? gains[row * T + t] : 1.0f;
+            const float raw = 1.0f - strength * (g - 1.0f);
+            const float scale = fminf(fmaxf(raw, 0.5f), 1.5f);
+            const bool scale_live = mod && raw >= 0.5f && raw <= 1.5f;   // torch.clamp passes the gradient at the bounds
+            const float ae = mod ? p.alpha * g : p.alpha;
+            float gg = 0.0f;                                             // this lane's share of dL/dgains[row][t]
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const float te = mod ? thp[e] * scale : thp[e];
+                const float cl = p.Lf * te * 2.0f;
+                const float b = fminf(fmaxf(a[e], -cl), cl);
+                const float n = b / te;
+                const float s = fminf(fmaxf(floorf(n), 0.0f), p.Lf);
+                float gth_prev = gth[e];
+                float gs_tot = gs[e];
+                if (p.alpha > 0.0f) {
+                    gs_tot = gs_tot + ae * gth[e];
+                    gth_prev = gth_prev - ae * gth[e];
+                    if (mod) gg += gth[e] * (s - (thp[e] - p.thr0)) * p.alpha;
+                }
+                gs_tot = gs_tot - te * gv[e];                            // v_t = b - s te
+                float gte = -s * gv[e];
+                float gb = gv[e];
+                const float dist = fabsf(n - rintf(n));
+                const float tri = fminf(fmaxf(1.0f - 2.0f * dist, 0.0f), 1.0f);
+                const float sur = (n >= 0.0f && n <= p.Lf + 1.0f) ? tri : 0.0f;
+                const float gn = gs_tot * sur;
+                gb = gb + gn / te;
+                gte = gte + (-gn * b / (te * te));
+                float ga = 0.0f, gcl = 0.0f;
+                if (a[e] < -cl) gcl = -gb;
+                else if (a[e] > cl) gcl = gb;
+                else ga = gb;
+                gte = gte + gcl * (2.0f * p.Lf);
+                gth_prev = gth_prev + (mod ? gte * scale : gte);
+                if (scale_live) gg += gte * thp[e] * (-strength);
+                gh[e] = mod ? ga * g : ga;
+                if (mod) gg += ga * x[e];
+                gv[e] = ga * p.decay;
+                gth[e] = gth_prev;
+            }
+            V<VEC>::st(g_h + o, gh);
+            if (mod && g_gains) atomicAdd(g_gains + row * T + t, gg);
+        }
+        V<VEC>::st(gv_io + row * C + c0, gv);
+        V<VEC>::st(gth_io + row * C + c0, gth);
+    }
+}
+
 }  // namespace
 
 #define AURA_VEC_DISPATCH(KERNEL, ITEMS4, ITEMS1, VECOK, ...)                                       \
@@ -328,6 +455,38 @@ int aura_gif_prosody_run(const float* h, const float* gains, float* spikes, floa
     const GifP p{decay, (float)L, alpha, threshold};
     AURA_VEC_DISPATCH(gif_prosody_kernel, rows * (H / 4), rows * H, vec, p, strength, h, gains, spikes, v,
                       theta, rows, T, H);
+    return check_launch();
+}
+
+int aura_gif_prosody_train_forward(const float* h, const float* gains, float* spikes, float* v, float* theta,
+                                   float* save_a, float* save_theta, float decay, int L, float alpha,
+                                   float threshold, float strength, int64_t rows, int64_t T, int64_t H,
+                                   void* stream) {
+    if (rows < 0 || T < 0 || H < 0 || L < 0) return AURA_E_INVAL;
+    if (rows == 0 || H == 0) return AURA_OK;
+    if (!v || !theta || (T && (!h || !spikes || !save_a || !save_theta))) return AURA_E_INVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool vec = H % 4 == 0 && aligned16(h) && aligned16(spikes) && aligned16(v) && aligned16(theta) &&
+                     aligned16(save_a) && aligned16(save_theta);
+    const GifP p{decay, (float)L, alpha, threshold};
+    AURA_VEC_DISPATCH(gif_prosody_train_fwd_kernel, rows * (H / 4), rows * H, vec, p, strength, h, gains, spikes,
+                      v, theta, save_a, save_theta, rows, T, H);
+    return check_launch();
+}
+
+int aura_gif_prosody_backward(const float* save_a, const float* save_theta, const float* h, const float* gains,
+                              const float* g_spikes, float* g_h, float* g_gains, float* g_v, float* g_theta,
+                              float decay, int L, float alpha, float threshold, float strength, int64_t rows,
+                              int64_t T, int64_t H, void* stream) {
+    if (rows < 0 || T < 0 || H < 0 || L < 0) return AURA_E_INVAL;
+    if (rows == 0 || H == 0) return AURA_OK;
+    if (!g_v || !g_theta || (T && (!save_a || !save_theta || !h || !g_spikes || !g_h))) return AURA_E_INVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool vec = H % 4 == 0 && aligned16(save_a) && aligned16(save_theta) && aligned16(h) &&
+                     aligned16(g_spikes) && aligned16(g_h) && aligned16(g_v) && aligned16(g_theta);
+    const GifP p{decay, (float)L, alpha, threshold};
+    AURA_VEC_DISPATCH(gif_prosody_bwd_kernel, rows * (H / 4), rows * H, vec, p, strength, save_a, save_theta, h,
+                      gains, g_spikes, g_h, g_gains, g_v, g_theta, rows, T, H);
     return check_launch();
 }
 

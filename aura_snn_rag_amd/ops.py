@@ -197,6 +197,31 @@ def gif_prosody_run(h, gains, spikes, v, theta, decay: float, L: int, alpha: flo
                                      threshold, strength, rows, T, H, _stream()), "aura_gif_prosody_run")
 
 
+def gif_prosody_train_forward(h, gains, spikes, v, theta, save_a, save_theta, decay: float, L: int, alpha: float,
+                              threshold: float, strength: float) -> None:
+    rows, T, H = h.shape
+    _same_f32((rows, T, H), (h, "h"), (spikes, "spikes"), (save_a, "save_a"), (save_theta, "save_theta"))
+    _same_f32((rows, H), (v, "v"), (theta, "theta"))
+    if gains is not None:
+        _same_f32((rows, T), (gains, "gains"))
+    check(lib().aura_gif_prosody_train_forward(_p(h), _p(gains), _p(spikes), _p(v), _p(theta), _p(save_a),
+                                               _p(save_theta), decay, int(L), alpha, threshold, strength, rows, T, H,
+                                               _stream()), "aura_gif_prosody_train_forward")
+
+
+def gif_prosody_backward(save_a, save_theta, h, gains, g_spikes, g_h, g_gains, g_v, g_theta, decay: float, L: int,
+                         alpha: float, threshold: float, strength: float) -> None:
+    """g_gains [rows, T] must be zero on entry (channels are accumulated into it)."""
+    rows, T, H = save_a.shape
+    _same_f32((rows, T, H), (save_a, "save_a"), (save_theta, "save_theta"), (h, "h"), (g_spikes, "g_spikes"), (g_h, "g_h"))
+    _same_f32((rows, H), (g_v, "g_v"), (g_theta, "g_theta"))
+    if gains is not None:
+        _same_f32((rows, T), (gains, "gains"), (g_gains, "g_gains"))
+    check(lib().aura_gif_prosody_backward(_p(save_a), _p(save_theta), _p(h), _p(gains), _p(g_spikes), _p(g_h),
+                                          _p(g_gains), _p(g_v), _p(g_theta), decay, int(L), alpha, threshold, strength,
+                                          rows, T, H, _stream()), "aura_gif_prosody_backward")
+
+
 # ---------------------------------------------------------------------------------------
 # episodic bank
 # ---------------------------------------------------------------------------------------

@@ -316,6 +316,20 @@ int aura_gif_prosody_run(const float* h, const float* gains, float* spikes, floa
                          float decay, int L, float alpha, float threshold, float strength,
                          int64_t rows, int64_t T, int64_t H, void* stream);
 
+/* Training forward / backward of that loop: as aura_gif_train_forward / aura_gif_backward with the
+ * gains; additionally g_gains [rows][T] receives dL/d gains (ZEROED by the caller; channels are summed
+ * with float atomics): through the input gain, the threshold scale (where its clamp is inactive) and the
+ * adaptation rate.  h = the currents of the forward pass.  Backward of prosody_gif.py:69-106 with
+ * MultiBitSurrogate (gif_neuron.py:16-22). */
+int aura_gif_prosody_train_forward(const float* h, const float* gains, float* spikes, float* v, float* theta,
+                                   float* save_a, float* save_theta, float decay, int L, float alpha,
+                                   float threshold, float strength, int64_t rows, int64_t T, int64_t H,
+                                   void* stream);
+int aura_gif_prosody_backward(const float* save_a, const float* save_theta, const float* h, const float* gains,
+                              const float* g_spikes, float* g_h, float* g_gains, float* g_v, float* g_theta,
+                              float decay, int L, float alpha, float threshold, float strength, int64_t rows,
+                              int64_t T, int64_t H, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Brain-zone projection
  * ------------------------------------------------------------------------------------- */

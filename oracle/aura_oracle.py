@@ -525,3 +525,28 @@ def prosody_gif_run(h, v, theta, gains, decay, L, alpha, threshold, strength):
             theta = theta + a_eff * spike - a_eff * (theta - threshold)
         out.append(spike)
     return torch.stack(out, dim=1), v, theta
+
+
+def prosody_gif_run_grad(h, v, theta, gains, decay, L, alpha, threshold, strength):
+    """``prosody_gif_run`` with autograd through ``MultiBitSurrogate``: the graph ``ProsodyModulatedGIF.forward``
+    builds (``prosody_gif.py:64-106``) when its inputs require grad (fp32)."""
+    out = []
+    for t in range(h.shape[1]):
+        i_t = h[:, t, :]
+        if gains is not None:
+            g = gains[:, t].unsqueeze(1)
+            i_t = i_t * g
+        v = v * decay + i_t
+        th_eff = theta
+        if gains is not None:
+            scale = torch.clamp(1.0 - strength * (g - 1.0), 0.5, 1.5)
+            th_eff = theta * scale
+        cl = L * th_eff * 2.0
+        v = torch.clamp(v, -cl, cl)
+        spike = MultiBitSurrogateFn.apply(v / th_eff, L)
+        v = v - spike * th_eff
+        if alpha > 0:
+            a_eff = alpha * g if gains is not None else alpha
+            theta = theta + a_eff * spike - a_eff * (theta - threshold)
+        out.append(spike)
+    return torch.stack(out, dim=1), v, theta

@@ -180,8 +180,29 @@ def test_prosody_gif_module(dev, B, T, I, H):
             rs2, rv2, rt2 = O.prosody_gif_run(h, rv, rt, None if gn is None else gn.cpu(), pg.decay, 8, 0.05,
                                               pg.threshold, 0.3)
             assert torch.equal(s2.cpu(), rs2) and torch.equal(v2.cpu(), rv2) and torch.equal(t2.cpu(), rt2)
-    with pytest.raises(NotImplementedError):
-        pg(x)                                            # parameters require grad, grad mode on
+    # surrogate-gradient backward (aura_gif_prosody_backward) against the oracle's autograd restatement, which
+    # is bit-equal to the reference's own graph (tests/test_oracle_vs_reference.py): input, gains, carried state
+    # and the linear layer
+    for use_gains in (True, False):
+        xg = (torch.randn(B, T, I) * 3)
+        gn = (0.2 + 3.0 * torch.rand(B, T)) if use_gains else None
+        v0 = 0.5 * torch.randn(B, H)
+        t0 = 1 + 0.3 * torch.rand(B, H)
+        ws = torch.randn(B, T, H)
+        cpu = [t.clone().requires_grad_(True) for t in (xg, v0, t0)] + ([gn.clone().requires_grad_(True)] if use_gains else [])
+        w_cpu = pg.linear.weight.detach().cpu().clone().requires_grad_(True)
+        b_cpu = pg.linear.bias.detach().cpu().clone()
+        os_, ov, ot = O.prosody_gif_run_grad(torch.nn.functional.linear(cpu[0], w_cpu, b_cpu), cpu[1], cpu[2],
+                                             cpu[3] if use_gains else None, pg.decay, 8, 0.05, pg.threshold, 0.3)
+        ref = torch.autograd.grad((os_ * ws).sum() + ov.sum() - ot.sum(), cpu + [w_cpu])
+        gpu = [t.to(dev).requires_grad_(True) for t in (xg, v0, t0)] + ([gn.to(dev).requires_grad_(True)] if use_gains else [])
+        s, (v, th) = pg(gpu[0], state=(gpu[1], gpu[2]), attention_gains=gpu[3] if use_gains else None)
+        got = torch.autograd.grad((s * ws.to(dev)).sum() + v.sum() - th.sum(), gpu + [pg.linear.weight])
+        # the spikes may differ where the GPU's GEMM rounds a current differently: compare gradients only if they agree
+        if torch.equal(s.detach().cpu(), os_.detach()):
+            for a, b in zip(got, ref):
+                assert torch.allclose(a.cpu(), b, rtol=2e-4, atol=2e-4 * max(1.0, float(b.abs().max()))), \
+                    float((a.cpu() - b).abs().max())
     with pytest.raises(ValueError):
         with torch.no_grad():
             pg(x, attention_gains=gains[:, :-1])

@@ -179,6 +179,19 @@ def test_surrogate_gradients_and_prosody_bit_exact():
             os_, ov, ot = O.prosody_gif_run(pg.linear(x), torch.zeros(3, 20), torch.full((3, 20), pg.threshold),
                                             gn, pg.decay, 8, 0.02, pg.threshold, 0.4)
             assert torch.equal(rs, os_) and torch.equal(rv, ov) and torch.equal(rt, ot)
+    # ... and its autograd graph: gradients w.r.t. input, gains, carried state and the linear layer
+    for use_gains in (True, False):
+        xg = (torch.randn(3, 7, 8) * 3).requires_grad_(True)
+        gg = (0.5 + 2.5 * torch.rand(3, 7)).requires_grad_(True) if use_gains else None
+        v0 = (0.5 * torch.randn(3, 20)).requires_grad_(True)
+        t0 = (1 + 0.3 * torch.rand(3, 20)).requires_grad_(True)
+        ws = torch.randn(3, 7, 20)
+        wrt = [xg, v0, t0, pg.linear.weight] + ([gg] if use_gains else [])
+        rs, (rv, rt) = pg(xg, state=(v0, t0), attention_gains=gg)
+        ref = torch.autograd.grad((rs * ws).sum() + rv.sum() - rt.sum(), wrt)
+        os_, ov, ot = O.prosody_gif_run_grad(pg.linear(xg), v0, t0, gg, pg.decay, 8, 0.02, pg.threshold, 0.4)
+        mine = torch.autograd.grad((os_ * ws).sum() + ov.sum() - ot.sum(), wrt)
+        assert torch.equal(rs, os_) and all(torch.equal(a, b) for a, b in zip(ref, mine))
 
 
 @pytest.mark.parametrize("mode", ["cross_attention", "concat", "gate"])
