@@ -200,10 +200,19 @@ def secondary_neurons(dev):
     vv = torch.zeros(rows, H, device=dev, dtype=torch.bfloat16); th = torch.ones_like(vv)
     ms = timed_events(lambda: ops.gif_run(h, out, vv, th, math.exp(-0.1), 8, 0.01, 1.0, T3))
     bytes_alg = rows * T3 * H * 4 + rows * H * 8
+    # the bf16 loop is bound by vector instructions (the reference's bf16 tensors round after every op: 13
+    # roundings per step; ~40 VALU instructions per neuron-step at 16 lanes/clk/SIMD for unpacked fp32 ops)
+    ms_core = timed_events(lambda: ops.gif_run(h[:, 0].contiguous(), out[:, 0].contiguous(), vv, th, math.exp(-0.1), 8,
+                                               0.01, 1.0, T3, time_invariant=True, mean_out=True))
+    valu_peak = 256 * 4 * 16 * 2.4e9                       # lane-ops/s: 256 CUs x 4 SIMDs x 16 lanes/clk (non-packed fp32)
     res["gif_bf16"] = {"rows": rows, "timesteps": T3, "hidden": H, "dtype": "bf16",
                        "neuron_timesteps_per_s": rows * T3 * H / (ms * 1e-3), "ms": ms, "algorithmic_bytes": bytes_alg,
                        "hbm_gbs": bytes_alg / (ms * 1e-3) / 1e9,
-                       "hbm_frac_of_8TBs": bytes_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                       "hbm_frac_of_8TBs": bytes_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                       "bound": "valu", "valu_instructions_per_neuron_step": 40,
+                       "valu_frac_of_peak": rows * T3 * H * 40 / (ms * 1e-3) / valu_peak,
+                       "ms_without_streams": ms_core,
+                       "valu_frac_of_peak_without_streams": rows * T3 * H * 40 / (ms_core * 1e-3) / valu_peak}
     del h, out, vv, th
     from aura_snn_rag_amd.core.language_zone.snn_ffn import SNNFFN
     torch.manual_seed(0)
