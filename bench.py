@@ -366,13 +366,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world == 1 and args.gpus > 1:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # AURA_BENCH_BACKEND=gloo: functional rehearsal of the N > 1 path on a box with fewer GPUs than ranks
+    # (ranks share devices, collectives go through gloo); the measured configuration is always nccl = RCCL
+    backend = os.environ.get("AURA_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     use_dist = world > 1 or os.environ.get("AURA_BENCH_FORCE_DIST") == "1"   # 1-rank RCCL smoke test
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from aura_snn_rag_amd import _lib
     from aura_snn_rag_amd.sharded import ShardedHippocampus
@@ -444,6 +452,7 @@ def main():
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
+        "collective_backend": (backend if use_dist else None),
         "config": {"workload": f"episodic cosine-kNN, {mode}: {total}x{D} fp32 bank "
                                f"({'row-sharded over %d ranks, %d rows each' % (world, rows) if world > 1 else 'one GPU'}), "
                                f"{nq}-query batch per rank and step, top-{k}, through HippocampalFormation.recall_batch "
