@@ -1666,8 +1666,50 @@ inline int launch_refine_for(const RefineArgs& r, int nqb, int64_t D, int cus, h
         hipLaunchKernelGGL((coarse_refine_kernel<ROWS, KC>), dim3((unsigned)nqb), dim3(RF_THREADS), lds, s, r);
         return check_launch();
     };
+    static const int geom = getenv("AURA_RF_GEOM") ? atoi(getenv("AURA_RF_GEOM")) : 0;   // A/B runs
+    if (geom == 1) return launch_refine(std::integral_constant<int, 8>{}, std::integral_constant<int, 128>{});
+    if (geom == 2) return launch_refine(std::integral_constant<int, 6>{}, std::integral_constant<int, 128>{});
+    if (geom == 3) return launch_refine(std::integral_constant<int, 16>{}, std::integral_constant<int, 256>{});
     if (nqb > cus) return launch_refine(std::integral_constant<int, 10>{}, std::integral_constant<int, 192>{});
     return launch_refine(std::integral_constant<int, 16>{}, std::integral_constant<int, 256>{});
+}
+
+// AURA_CS_DBG bit 64: per-wave phase times of a filter launch (written by the kernel into `buf`)
+inline void print_cs_phases(hipStream_t s, const float* buf, int cus) {
+    (void)hipStreamSynchronize(s);
+    std::vector<float> h((size_t)cus * 64);
+    (void)hipMemcpy(h.data(), buf, h.size() * 4, hipMemcpyDeviceToHost);
+    static const char* const names[6] = {"wait+barrier", "check+issue", "-", "mfma loop", "write-out", "epilogue"};
+    for (int role = 0; role < 2; ++role) {
+        double sum[6] = {0, 0, 0, 0, 0, 0}, tiles = 0; int waves = 0;
+        for (int g = 0; g < cus; ++g)
+            for (int wv = role * 4; wv < role * 4 + 4; ++wv) {
+                const float* o = &h[((size_t)g * 8 + wv) * 8];
+                if (o[6] <= 0) continue;
+                for (int i = 0; i < 6; ++i) sum[i] += o[i];
+                tiles += o[6]; ++waves;
+            }
+        if (!waves) continue;
+        fprintf(stderr, "[cs phases] waves %d-%d: %d waves, %.1f tiles each;", role * 4, role * 4 + 3, waves, tiles / waves);
+        double tot = 0;
+        for (int i = 0; i < 6; ++i) {
+            fprintf(stderr, " %s %.2f us (%.0f ns/tile);", names[i], sum[i] / waves * 0.01, sum[i] / tiles * 10.0);
+            tot += sum[i];
+        }
+        fprintf(stderr, " total %.2f us\n", tot / waves * 0.01);
+    }
+    // whole-kernel time per workgroup (wave 0), tile-loop time, tiles: spread over the workgroups
+    double kmin = 1e30, kmax = 0, ksum = 0, lmin = 1e30, lmax = 0, lsum = 0; int n = 0;
+    for (int g = 0; g < cus; ++g) {
+        const float* o = &h[(size_t)g * 64];
+        if (o[6] <= 0) continue;
+        double l = 0; for (int i = 0; i < 6; ++i) l += o[i];
+        const double kt = o[7];
+        kmin = kt < kmin ? kt : kmin; kmax = kt > kmax ? kt : kmax; ksum += kt;
+        lmin = l < lmin ? l : lmin; lmax = l > lmax ? l : lmax; lsum += l; ++n;
+    }
+    if (n) fprintf(stderr, "[cs phases] per workgroup: kernel time min %.1f mean %.1f max %.1f us; tile loops min %.1f mean %.1f max %.1f us\n",
+                   kmin * 0.01, ksum / n * 0.01, kmax * 0.01, lmin * 0.01, lsum / n * 0.01, lmax * 0.01);
 }
 
 // Two-stage recall of one query pass (see aura_knn_coarse.inl).  Returns AURA_OK after queuing
@@ -1755,28 +1797,7 @@ inline int run_coarse_pass(const float* bank, const uint16_t* bank16, const floa
     if (prof) (void)hipEventRecord(g_prof.stop[g_prof.used++], s);
     if (tm) {
         --tm_left;
-        (void)hipStreamSynchronize(s);
-        std::vector<float> h((size_t)cus * 64);
-        (void)hipMemcpy(h.data(), w.gmax, h.size() * 4, hipMemcpyDeviceToHost);
-        static const char* const names[6] = {"wait+barrier", "check+issue", "-", "mfma loop", "write-out", "epilogue"};
-        for (int role = 0; role < 2; ++role) {
-            double sum[6] = {0, 0, 0, 0, 0, 0}, tiles = 0; int waves = 0;
-            for (int g = 0; g < cus; ++g)
-                for (int wv = role * 4; wv < role * 4 + 4; ++wv) {
-                    const float* o = &h[((size_t)g * 8 + wv) * 8];
-                    if (o[6] <= 0) continue;
-                    for (int i = 0; i < 6; ++i) sum[i] += o[i];
-                    tiles += o[6]; ++waves;
-                }
-            if (!waves) continue;
-            fprintf(stderr, "[cs phases] waves %d-%d: %d waves, %.1f tiles each;", role * 4, role * 4 + 3, waves, tiles / waves);
-            double tot = 0;
-            for (int i = 0; i < 6; ++i) {
-                fprintf(stderr, " %s %.2f us (%.0f ns/tile);", names[i], sum[i] / waves * 0.01, sum[i] / tiles * 10.0);
-                tot += sum[i];
-            }
-            fprintf(stderr, " total %.2f us\n", tot / waves * 0.01);
-        }
+        print_cs_phases(s, w.gmax, cus);
     }
 
     RefineArgs r{};
@@ -2109,6 +2130,17 @@ int aura_knn_search_ivf2(const float* bank, const float* inv_norm, const float* 
             fflush(stderr);
         }
     };
+    static const bool w4 = getenv("AURA_CS_WAVES4") != nullptr;   // A/B runs: one wave per SIMD
+    // Relative time of a filter tile in a block of <= 128 queries and in a fuller one (the one- and the
+    // two-column-block form of the tile loop): the plan splits tiles x weight evenly over the workgroups.
+    // AURA_IVF_W=s,d overrides (tuning runs); the one-wave-per-SIMD form has a single tile loop.
+    static int w_sparse = 0, w_dense = 0;
+    if (w_sparse == 0) {
+        int ws = 3, wd = 4;
+        if (const char* e = getenv("AURA_IVF_W")) { if (sscanf(e, "%d,%d", &ws, &wd) != 2 || ws < 1 || wd < 1 || ws > 64 || wd > 64) { ws = 3; wd = 4; } }
+        if (w4) ws = wd = 1;
+        w_dense = wd; w_sparse = ws;
+    }
     for (int64_t qb0 = 0; qb0 < nq; qb0 += w.qp) {
         const int nqb = (int)((nq - qb0) < w.qp ? (nq - qb0) : w.qp);
         const float* qptr = queries + qb0 * D;
@@ -2121,7 +2153,8 @@ int aura_knn_search_ivf2(const float* bank, const float* inv_norm, const float* 
         if ((rc = check_launch())) return rc;
         stage("prepare");
         hipLaunchKernelGGL(ivf2_plan_kernel, dim3(1), dim3(256), 0, s, w.lq_cnt, pad_off, list_len, w.blk_off,
-                           w.blk_list, w.blk_row0, w.blk_stride, w.item_off, w.sitem_off, w.nblk);
+                           w.blk_list, w.blk_row0, w.blk_stride, w.blk_nq, w.item_off, w.sitem_off, w.nblk,
+                           w_sparse, w_dense);
         if ((rc = check_launch())) return rc;
         stage("plan");
         const int qblocks = IVF2_MAXBLK * 256 / 4;
@@ -2138,10 +2171,10 @@ int aura_knn_search_ivf2(const float* bank, const float* inv_norm, const float* 
         c.N = n_sorted; c.D = D; c.nq = IVF2_MAXBLK * 256;
         c.thr = w.thr; c.cnt = w.cnt; c.cand_scores = w.cand_scores; c.cand_idx = w.cand_idx; c.cap = w.cap;
         c.blk_row0 = w.blk_row0; c.blk_stride = w.blk_stride; c.nblk = w.nblk; c.slotq = w.slotq;
+        c.blk_nq = w.blk_nq; c.w_sparse = w_sparse; c.w_dense = w_dense;
         c.gmax = w.gmax; c.gmax_ld = 2 * IVF2_STILES; c.item_off = w.sitem_off;
         static const int cs_dbg = getenv("AURA_CS_DBG") ? atoi(getenv("AURA_CS_DBG")) : 0;
         c.dbg = cs_dbg;
-        static const bool w4 = getenv("AURA_CS_WAVES4") != nullptr;   // A/B runs: one wave per SIMD
         auto launch = [&](int mode) -> int {
             if (w4) {
                 if (KS == 8) return launch_coarse_ivf<8, 4>(c, mode, cus, s);
@@ -2159,6 +2192,12 @@ int aura_knn_search_ivf2(const float* bank, const float* inv_norm, const float* 
         if ((rc = check_launch())) return rc;
         stage("threshold");
         c.gmax = nullptr; c.item_off = w.item_off;
+        static int tm_left2 = 2;                             // AURA_CS_DBG bit 64: phase times of the first launches
+        const bool tm2 = (cs_dbg & 64) && tm_left2 > 0;
+        if (tm2) {
+            c.gmax = w.gmax;
+            (void)hipMemsetAsync(w.gmax, 0, (size_t)cus * 8 * 8 * 4, s);
+        }
         const bool prof = g_prof.on && g_prof.used < g_prof.cap;
         if (prof) {
             (void)hipEventRecord(g_prof.start[g_prof.used], s);
@@ -2168,6 +2207,23 @@ int aura_knn_search_ivf2(const float* bank, const float* inv_norm, const float* 
         if ((rc = launch(CS_MODE_FILTER))) return rc;
         if (prof) (void)hipEventRecord(g_prof.stop[g_prof.used++], s);
         stage("filter scan");
+        if (tm2) {
+            --tm_left2;
+            print_cs_phases(s, w.gmax, cus);
+            std::vector<int32_t> lq(256);
+            (void)hipMemcpy(lq.data(), w.lq_cnt, 256 * 4, hipMemcpyDeviceToHost);
+            std::vector<int32_t> ll(256);
+            (void)hipMemcpy(ll.data(), list_len, 256 * 4, hipMemcpyDeviceToHost);
+            long rows_le64 = 0, rows_le128 = 0, rows_le256 = 0, rows_more = 0, reads = 0;
+            for (int c2 = 0; c2 < 256; ++c2) {
+                const long blocks = (lq[c2] + 255) / 256;
+                reads += blocks * ll[c2];
+                if (lq[c2] <= 64) rows_le64 += ll[c2]; else if (lq[c2] <= 128) rows_le128 += ll[c2];
+                else if (lq[c2] <= 256) rows_le256 += ll[c2]; else rows_more += ll[c2];
+            }
+            fprintf(stderr, "[ivf2] rows in lists probed by <=64 / <=128 / <=256 / >256 queries: %ld / %ld / %ld / %ld; row reads %ld\n",
+                    rows_le64, rows_le128, rows_le256, rows_more, reads);
+        }
 
         RefineArgs r{};
         r.bank = bank; r.inv_norm = inv_norm; r.meta = meta; r.queries = qptr; r.inv_q = w.inv_q;

@@ -54,6 +54,9 @@ constexpr int CS_THREADS = 256;           // 4 waves (one per SIMD, 512 register
 constexpr int CS_QB = 4;                 // 16-query MFMA column blocks per wave
 constexpr int CS_ROWS = 16;              // bank rows per tile
 constexpr int CS_SLOTS = 3;
+#ifndef CS_PF_SPARSE
+#define CS_PF_SPARSE 6                  // LDS read-ahead (k-steps) of the one-column-block tile loop
+#endif
 constexpr int CS_AUX_BYTES = 1024;       // per slot: row constants (64 lanes x 16 B, first 16 used)
 constexpr int CS_BUF = 1024;             // candidate entries buffered per workgroup (two halves of 512)
 constexpr int CS_FLUSH_MIN = 128;        // a stable half is written out once it holds this many
@@ -102,6 +105,8 @@ struct CoarseArgs {
     const int32_t* item_off;
     const int32_t* nblk;     // [1]
     const int32_t* slotq;    // [nblk * 256]
+    const int32_t* blk_nq;   // [nblk] query slots in use in block B (the rest of its 256 are padding)
+    int w_sparse, w_dense;   // IVF filter: item_off counts tiles x these weights (block of <= 128 / more queries)
     int dbg;                 // AURA_CS_DBG timing ablations (results invalid when non-zero)
 };
 
@@ -228,8 +233,36 @@ __device__ __forceinline__ uint32_t cs_swz32(uint32_t row) {
 #endif
 }
 
-template <bool QA, bool LAST, bool PAD>
-__device__ __forceinline__ void mfma_bf16_q(f32x4v& acc, const bf16x8v& af, const bf16x8v& q) {
+template <bool QA, bool LAST, bool PAD, bool COND = false>
+__device__ __forceinline__ void mfma_bf16_q(f32x4v& acc, const bf16x8v& af, const bf16x8v& q, int on = 1) {
+    // COND: the MFMA runs only when `on` (wave-uniform, in an SGPR) is non-zero -- a scalar compare and
+    // branch inside the statement, so the compiler sees one definition of the accumulator either way.
+    if constexpr (COND) {
+#define AURA_SKIP_IN "s_cmp_eq_u32 %3, 0\n\ts_cbranch_scc1 .Laura_skip%=\n\t"
+#define AURA_SKIP_OUT "\n.Laura_skip%=:"
+#define AURA_NOP1C "s_nop 1\n\t"
+#define AURA_MFMAC "v_mfma_f32_16x16x32_bf16 "
+        if constexpr (PAD) {
+            if constexpr (QA && LAST)
+                asm volatile(AURA_SKIP_IN AURA_NOP1C AURA_MFMAC "%0, %1, %2, %0\n\ts_nop 7\n\ts_nop 4" AURA_SKIP_OUT : "+a"(acc) : "v"(af), "a"(q), "s"(on) : "scc");
+            else if constexpr (QA)
+                asm volatile(AURA_SKIP_IN AURA_NOP1C AURA_MFMAC "%0, %1, %2, %0" AURA_SKIP_OUT : "+a"(acc) : "v"(af), "a"(q), "s"(on) : "scc");
+            else if constexpr (LAST)
+                asm volatile(AURA_SKIP_IN AURA_NOP1C AURA_MFMAC "%0, %1, %2, %0\n\ts_nop 7\n\ts_nop 4" AURA_SKIP_OUT : "+a"(acc) : "v"(af), "v"(q), "s"(on) : "scc");
+            else
+                asm volatile(AURA_SKIP_IN AURA_NOP1C AURA_MFMAC "%0, %1, %2, %0" AURA_SKIP_OUT : "+a"(acc) : "v"(af), "v"(q), "s"(on) : "scc");
+        } else {
+            if constexpr (QA && LAST)
+                asm volatile(AURA_SKIP_IN AURA_MFMAC "%0, %1, %2, %0\n\ts_nop 7\n\ts_nop 4" AURA_SKIP_OUT : "+a"(acc) : "v"(af), "a"(q), "s"(on) : "scc");
+            else if constexpr (QA)
+                asm volatile(AURA_SKIP_IN AURA_MFMAC "%0, %1, %2, %0" AURA_SKIP_OUT : "+a"(acc) : "v"(af), "a"(q), "s"(on) : "scc");
+            else if constexpr (LAST)
+                asm volatile(AURA_SKIP_IN AURA_MFMAC "%0, %1, %2, %0\n\ts_nop 7\n\ts_nop 4" AURA_SKIP_OUT : "+a"(acc) : "v"(af), "v"(q), "s"(on) : "scc");
+            else
+                asm volatile(AURA_SKIP_IN AURA_MFMAC "%0, %1, %2, %0" AURA_SKIP_OUT : "+a"(acc) : "v"(af), "v"(q), "s"(on) : "scc");
+        }
+        return;
+    }
     // PAD: s_nop 1 in front = the two wait states between a VALU write of an operand register and the
     // MFMA reading it (hipcc pads nothing inside inline asm).  The fp32-row kernels need it: their A
     // fragment comes out of v_cvt_pk_bf16_f32 right before.  The bf16-row kernels run without: the A
@@ -546,38 +579,70 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
         wc[0] = 0; wc[1] = 0;
     };
 
+    const uint32_t t_kernel0 = (MODE == CS_MODE_FILTER && (a.dbg & 64)) ? (uint32_t)__builtin_amdgcn_s_memrealtime() : 0u;
     int64_t c = lo;
+    int blk_cur = -1;                                      // IVF: block of the previous segment
     while (c < hi) {
         int64_t qblk, j0, seg;
         if (IVF) {
-            int blo = 0, bhi = ivf_nblk;                    // block B with item_off[B] <= c < item_off[B+1]
-            while (bhi - blo > 1) {
-                const int mid = (blo + bhi) >> 1;
-                if ((int64_t)a.item_off[mid] <= c) blo = mid; else bhi = mid;
+            // The span [lo, hi) is in work units: item_off counts tiles x the block's weight (filter
+            // scan; 1 otherwise).  Tile j of block B belongs to the workgroup whose span holds
+            // item_off[B] + j * weight.
+            int blo;
+            if (blk_cur < 0) {                              // block B with item_off[B] <= c < item_off[B+1]
+                int bhi = ivf_nblk;
+                blo = 0;
+                while (bhi - blo > 1) {
+                    const int mid = (blo + bhi) >> 1;
+                    if ((int64_t)a.item_off[mid] <= c) blo = mid; else bhi = mid;
+                }
+            } else {
+                blo = blk_cur + 1;                          // the previous segment ran to the end of its block
             }
+            blk_cur = blo;
             qblk = blo;
-            j0 = c - a.item_off[blo];
-            const int64_t left = (int64_t)a.item_off[blo + 1] - c;
-            seg = (hi - c) < left ? (hi - c) : left;
+            const int64_t base = a.item_off[blo], next = a.item_off[blo + 1];
+            const int64_t wgt = (MODE == CS_MODE_FILTER) ? (a.blk_nq[blo] <= 128 ? a.w_sparse : a.w_dense) : 1;
+            const int64_t c_end = hi < next ? hi : next;
+            j0 = (c - base + wgt - 1) / wgt;
+            seg = (c_end - base + wgt - 1) / wgt - j0;
+            c = c_end;
+            if (seg <= 0) continue;                         // (workgroup-uniform)
             ivf_row0 = a.blk_row0[blo];
             ivf_step = MODE == CS_MODE_SAMPLE ? 16 * (int64_t)a.blk_stride[blo] : 16;   // sample: spread over the list
         } else {
             qblk = c / a.n_tiles; j0 = c - qblk * a.n_tiles;
             seg = (hi - c) < (a.n_tiles - j0) ? (hi - c) : (a.n_tiles - j0);
+            c += seg;
         }
-        c += seg;
         const int qoff = (int)qblk * 256 + wave * (16 * QB);   // this wave's first query (IVF: block slot)
+        // Query slots in use in this block.  The interval between two tile barriers is ONE wave's serial
+        // work on a tile (DMA issue, MFMAs, epilogue), so the work of a sparse block must be spread over
+        // the waves, not packed into the first ones: the inverted-list prep deals a block's queries
+        // round-robin (query i -> wave i % 8, position i / 8; exact recall: natural order), and a block of
+        // at most 128 queries -- the common case at 8 probes of 256 lists -- runs the ONE-column-block
+        // form of the tile loop (run_segment<1>: 24 instead of 48 MFMAs and half the epilogue per wave
+        // and tile, the second block's fragment registers go to a deeper LDS read-ahead).  Waves without
+        // a query skip MFMAs and epilogue; they still issue their share of the LDS-DMA and meet the barrier.
+        const int n_used = IVF ? a.blk_nq[qblk] : (a.nq - (int)qblk * 256);
         if (IVF && MODE == CS_MODE_FILTER) {                // slot -> query table of this block -> LDS
             int32_t* const s_sq = reinterpret_cast<int32_t*>(csmem + NSLOT * SLOT_BYTES + CS_BUF * 12);
             if (tid < 256) s_sq[tid] = a.slotq[qblk * 256 + tid];
             __syncthreads();
         }
 
-        // ---- stationary operand: 64 (normalised) queries of this wave as bf16 B-fragments ----
+        auto run_segment = [&](auto NB_) {
+        constexpr int NBc = decltype(NB_)::value;           // column blocks (16 queries) per wave: QB, or 1 (sparse block)
+        int my_cnt = (IVF && NW == 8) ? (n_used - wave + 7) / 8 : n_used - wave * (16 * QB);
+        my_cnt = my_cnt < 0 ? 0 : (my_cnt > 16 * NBc ? 16 * NBc : my_cnt);
+        // column blocks this wave runs (wave-uniform, in a scalar register)
+        const int nb = __builtin_amdgcn_readfirstlane(NBc == 2 ? (my_cnt + 15) / 16 : (my_cnt > 0 ? NBc : 0));
+        const bool wave_active = nb > 0;
+        // ---- stationary operand: the (normalised) queries of this wave as bf16 B-fragments ----
         // one coalesced 16-byte load per lane and fragment, all in flight at once, landing in
         // their final registers
-        bf16x8v qf[QB][KS];
-        float thrf[QB];
+        bf16x8v qf[NBc][KS];
+        float thrf[NBc];
         if (MASKED) {                                       // this block's probe masks -> LDS
             uint32_t* const s_mask = reinterpret_cast<uint32_t*>(csmem + NSLOT * SLOT_BYTES + CS_BUF * 12);
             for (int i = tid; i < 256 * 8; i += THREADS) {
@@ -597,20 +662,20 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
             __syncthreads();
         }
         if (MODE == CS_MODE_FILTER) {                       // thresholds first: their wait must not
-            uint32_t key[QB];                              // sit between the fragment loads
+            uint32_t key[NBc];                             // sit between the fragment loads
 #pragma unroll
-            for (int b = 0; b < QB; ++b) {
+            for (int b = 0; b < NBc; ++b) {
                 const int q = qoff + 16 * b + lr;
                 key[b] = a.thr[q < a.nq ? q : a.nq - 1];
             }
 #pragma unroll
-            for (int b = 0; b < QB; ++b) thrf[b] = qoff + 16 * b + lr < a.nq ? ord_unkey(key[b]) : INFINITY;
+            for (int b = 0; b < NBc; ++b) thrf[b] = qoff + 16 * b + lr < a.nq ? ord_unkey(key[b]) : INFINITY;
         } else {
 #pragma unroll
-            for (int b = 0; b < QB; ++b) thrf[b] = INFINITY;
+            for (int b = 0; b < NBc; ++b) thrf[b] = INFINITY;
         }
 #pragma unroll
-        for (int b = 0; b < QB; ++b) {
+        for (int b = 0; b < NBc; ++b) {
             const uint16_t* qp = a.qhat + (((qblk * 16 + wave * QB + b) * KS) * 64 + lane) * 8;
 #pragma unroll
             for (int s = 0; s < KS; ++s)
@@ -621,7 +686,7 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
         issue(j0, 0);
         if (seg > 1) issue(j0 + 1, 1);
 #pragma unroll
-        for (int b = 0; b < QB; ++b) {
+        for (int b = 0; b < NBc; ++b) {
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 // pin each fragment in its register file (see mfma_bf16_q)
@@ -635,7 +700,7 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
         // (Measured dead end for the 8-wave kernels: waves 4-7 running one tile behind -- epilogue of
         // tile t-1 first, then tile t's MFMAs, so that the two waves of a SIMD are in opposite phases --
         // was 2-5 us SLOWER than letting both run in step: 65.6-68.8 vs 63.6 us at config 2.)
-        f32x4v acc[QB];
+        f32x4v acc[NBc];
         f32x4v rcv[4];                                       // constants of rows 4 lg .. 4 lg + 3
         int slot = 0;
         const int64_t n_int = seg;
@@ -655,13 +720,13 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
             const uint32_t ts1 = stamp();
             const int par = (int)(t & 1);
             // this wave's eq values: read here, consumed by the accumulator set-up behind the DMA issue
-            uint32_t eqr[QB];
+            uint32_t eqr[NBc];
             if (SRC16) {
                 uint32_t ln2 = (uint32_t)lane;
                 asm volatile("" : "+v"(ln2));                // recomputed per tile (see issue())
                 const uint32_t ea = eq_addr + (uint32_t)(wave * (16 * QB)) * 4u + (ln2 & 15u) * 4u;
 #pragma unroll
-                for (int b = 0; b < QB; ++b)
+                for (int b = 0; b < NBc; ++b)
                     asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(eqr[b]) : "v"(ea), "n"(64 * b) : "memory");
             }
             // The half tile t-1 appended to is stable during this tile.  Once it holds enough entries
@@ -687,15 +752,18 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
             if (SRC16) {
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(eqr[0])::"memory");
 #pragma unroll
-                for (int b = 1; b < QB; ++b) asm volatile("" : "+v"(eqr[b])::"memory");
+                for (int b = 1; b < NBc; ++b) asm volatile("" : "+v"(eqr[b])::"memory");
             }
 #pragma unroll
-            for (int b = 0; b < QB; ++b)
+            for (int b = 0; b < NBc; ++b)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[b][e] = SRC16 ? __uint_as_float(eqr[b]) : 0.0f;
             // fragment reads run two k-steps ahead of the MFMAs (one wave per SIMD: nothing else
             // hides the LDS latency)
-            constexpr int PF = (SRC16 && NW == 4) ? CS_PF16 : 2;   // k-steps the reads run ahead (8 waves: registers are short, the other wave hides the latency)
+            // k-steps the reads run ahead (8 waves: registers are short, the other wave hides the latency;
+            // the one-column-block form has the second block's registers to spend and half the MFMA time
+            // per step to hide the LDS latency behind)
+            constexpr int PF = (SRC16 && NW == 4) ? CS_PF16 : (NBc < QB ? CS_PF_SPARSE : 2);
             f32x4v xr[PF + 1][2];
             constexpr int RP = SRC16 ? 1 : 2;                // LDS reads per k-step
             constexpr int S_RC = KS >= 3 ? KS - 3 : 0;       // the row constants are fetched behind this step
@@ -729,16 +797,15 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
                     x[4] = x1[0]; x[5] = x1[1]; x[6] = x1[2]; x[7] = x1[3];
                     af = __builtin_convertvector(x, bf16x8v);
                 }
-#pragma unroll
-                for (int b = 0; b < QB; ++b) {
-                    if (b * KS + s < QA) {
-                        if (s == KS - 1) mfma_bf16_q<true, true, !SRC16>(acc[b], af, qf[b][s]);
-                        else mfma_bf16_q<true, false, !SRC16>(acc[b], af, qf[b][s]);
-                    } else {
-                        if (s == KS - 1) mfma_bf16_q<false, true, !SRC16>(acc[b], af, qf[b][s]);
-                        else mfma_bf16_q<false, false, !SRC16>(acc[b], af, qf[b][s]);
-                    }
-                }
+                cs_static_for<0, NBc>([&](auto Bc) {
+                    constexpr int b = decltype(Bc)::value;
+                    // exact recall, last query block: the second column block of a wave runs only when it
+                    // holds a query (the skip is a scalar branch inside the statement, so the accumulators
+                    // keep one definition)
+                    constexpr bool CND = !IVF && NBc == 2 && b == 1;
+                    constexpr bool INA = b * KS + s < QA;
+                    mfma_bf16_q<INA, s == KS - 1, !SRC16, CND>(acc[b], af, qf[b][s], nb - 1);
+                });
                 // the epilogue's row constants are fetched behind the last two k-steps
                 if constexpr (s == S_RC)
                     lds_read4x16_nowait(cs_base + slot * SLOT_BYTES + TILE_BYTES + lg * 64, rcv[0], rcv[1], rcv[2], rcv[3]);
@@ -754,12 +821,12 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
             // ---- epilogue: rows 4 lg + e of the tile, queries qoff + 16 b + lr ----
             const int64_t r0 = tile_row0(j0 + tt);
             const int rows_left = (int)((a.N - r0) < CS_ROWS ? (a.N - r0) : CS_ROWS);
-            float gm[QB];
-            float uv[4 * QB];                                // U of the tile's pairs (kept out of the AGPR accumulators)
+            float gm[NBc];
+            float uv[4 * NBc];                                // U of the tile's pairs (kept out of the AGPR accumulators)
             unsigned bits = 0u;
             if (!(a.dbg & 2)) {
 #pragma unroll
-            for (int b = 0; b < QB; ++b) gm[b] = -INFINITY;
+            for (int b = 0; b < NBc; ++b) gm[b] = -INFINITY;
             unsigned allow = 0xffffu;                        // bit 4 b + e: pair passes the probe mask
             if (MASKED) {
                 // 16 mask words (4 rows x 4 query blocks) by inline-asm LDS reads, one wait
@@ -796,8 +863,8 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
                 const f32x4v rc = rcv[e];
                 const bool vrow = 4 * lg + e < rows_left;
 #pragma unroll
-                for (int b = 0; b < QB; ++b) {
-                    const bool ok = vrow && ((allow >> (b * 4 + e)) & 1u);
+                for (int b = 0; b < NBc; ++b) {
+                    const bool ok = b < nb && vrow && ((allow >> (b * 4 + e)) & 1u);
                     if (MODE == CS_MODE_SAMPLE) {
                         gm[b] = fmaxf(gm[b], ok ? acc[b][e] * rc[0] + rc[2] : -INFINITY);
                     } else {
@@ -810,7 +877,7 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
             }
             if (MODE == CS_MODE_SAMPLE) {
 #pragma unroll
-                for (int b = 0; b < QB; ++b) {
+                for (int b = 0; b < NBc; ++b) {
                     float mx = gm[b];
                     mx = fmaxf(mx, __shfl_xor(mx, 16));
                     const int q = qoff + 16 * b + lr;
@@ -840,7 +907,7 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
                         const int idx = __ffs(rem) - 1;      // = 4 b + e
                         float u = uv[0];
 #pragma unroll
-                        for (int i = 1; i < 4 * QB; ++i) u = idx == i ? uv[i] : u;
+                        for (int i = 1; i < 4 * NBc; ++i) u = idx == i ? uv[i] : u;
                         const int p = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
                                           __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
                         int q = qoff + 16 * (idx >> 2) + lr;
@@ -872,7 +939,7 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
             };
             const uint32_t ts2 = stamp();
             const uint32_t ts3 = ts2;
-            mma();
+            if (wave_active) mma();
             const uint32_t ts4 = stamp();
             if (MODE == CS_MODE_FILTER && fl_n > 0) {       // second step of the write-out (wave-uniform)
                 if (t + 2 >= seg) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -894,7 +961,7 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
             }
 
             const uint32_t ts5 = stamp();
-            epi(t);
+            if (wave_active) epi(t);
             if (tm) {
                 const uint32_t ts6 = stamp();
                 tacc[0] += ts1 - ts0; tacc[1] += ts2 - ts1; tacc[2] += ts3 - ts2;
@@ -908,6 +975,9 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
             for (int i = 0; i < 6; ++i) o[i] += (float)tacc[i];
             o[6] += (float)seg;
         }
+        };
+        if (IVF && NW == 8 && QB == 2 && n_used <= 128 && !(a.dbg & 256)) run_segment(std::integral_constant<int, 1>{});
+        else run_segment(std::integral_constant<int, QB>{});
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (MODE == CS_MODE_FILTER) {                       // span end: both halves go out
@@ -916,6 +986,8 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
             __builtin_amdgcn_s_barrier();
         }
     }
+    if (MODE == CS_MODE_FILTER && (a.dbg & 64) && a.gmax != nullptr && lane == 0)   // whole-kernel time of this wave
+        a.gmax[((int64_t)blockIdx.x * 8 + wave) * 8 + 7] += (float)((uint32_t)__builtin_amdgcn_s_memrealtime() - t_kernel0);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -31,9 +31,11 @@ __global__ __launch_bounds__(256) void ivf2_plan_kernel(const int32_t* __restric
                                                         int32_t* blk_list,   // [MAXBLK] list of block B
                                                         int32_t* blk_row0,   // [MAXBLK]
                                                         int32_t* blk_stride, // [MAXBLK] tiles between sample tiles
-                                                        int32_t* item_off,   // [MAXBLK + 1] filter items
+                                                        int32_t* blk_nq,     // [MAXBLK] query slots in use
+                                                        int32_t* item_off,   // [MAXBLK + 1] filter work (tiles x block weight)
                                                         int32_t* sitem_off,  // [MAXBLK + 1] sample items
-                                                        int32_t* nblk) {
+                                                        int32_t* nblk,
+                                                        int w_sparse, int w_dense) {   // cost of a tile of a block of <= 128 / more queries
     __shared__ int s_nb[257];
     const int tid = threadIdx.x;
     s_nb[tid + 1] = (lq_cnt[tid] + 255) / 256;
@@ -51,15 +53,22 @@ __global__ __launch_bounds__(256) void ivf2_plan_kernel(const int32_t* __restric
     for (int b = s_nb[tid]; b < s_nb[tid + 1]; ++b) {
         blk_list[b] = tid;
         blk_row0[b] = pad_off[tid];
+        const int left = lq_cnt[tid] - (b - s_nb[tid]) * 256;
+        blk_nq[b] = left < 256 ? left : 256;
         blk_stride[b] = tiles > IVF2_STILES ? tiles / IVF2_STILES : 1;   // sample tiles j * stride, j < 32
     }
     __syncthreads();
-    // work-item prefixes: list c contributes (blocks of c) x (tiles of c) filter items and
-    // (blocks of c) x min(tiles, STILES) sample items; exclusive scan over the lists in LDS
+    // work prefixes: list c contributes (tiles of c) x (weights of its blocks) filter work and
+    // (blocks of c) x min(tiles, STILES) sample items; exclusive scan over the lists in LDS.  The filter
+    // scan splits the WORK evenly over its workgroups, and a tile of a block of at most 128 queries
+    // (one column block per wave, see coarse_scan_kernel) takes less time than one of a fuller block:
+    // all but the last block of a list hold 256 queries.
     __shared__ int s_it[257], s_st[257];
     const int nb = s_nb[tid + 1] - s_nb[tid];
     const int stl = tiles < IVF2_STILES ? tiles : IVF2_STILES;
-    s_it[tid + 1] = nb * tiles; s_st[tid + 1] = nb * stl;
+    const int last_left = lq_cnt[tid] - (nb - 1) * 256;
+    const int w_last = last_left <= 128 ? w_sparse : w_dense;
+    s_it[tid + 1] = nb > 0 ? tiles * ((nb - 1) * w_dense + w_last) : 0; s_st[tid + 1] = nb * stl;
     if (tid == 0) { s_it[0] = 0; s_st[0] = 0; }
     __syncthreads();
     for (int off = 1; off < 256; off <<= 1) {
@@ -70,7 +79,7 @@ __global__ __launch_bounds__(256) void ivf2_plan_kernel(const int32_t* __restric
         __syncthreads();
     }
     for (int b = s_nb[tid], j = 0; b < s_nb[tid + 1]; ++b, ++j) {
-        item_off[b] = s_it[tid] + j * tiles;
+        item_off[b] = s_it[tid] + j * tiles * w_dense;
         sitem_off[b] = s_st[tid] + j * stl;
     }
     if (tid == 0) { item_off[s_nb[256]] = s_it[256]; sitem_off[s_nb[256]] = s_st[256]; }
@@ -114,7 +123,10 @@ __global__ __launch_bounds__(256) void ivf2_prep_kernel(const float* __restrict_
     const int B = (int)(vs >> 8);
     if (B >= nblk[0]) return;
     const int list = blk_list[B];
-    const int ls = (B - blk_off[list]) * 256 + (int)(vs & 255);           // slot inside the list's query list
+    // slot = wave * 32 + position: a block's queries are dealt round-robin over the scan's 8 waves (query
+    // i of the block -> wave i % 8, position i / 8), see coarse_scan_kernel
+    const int slot = (int)(vs & 255);
+    const int ls = (B - blk_off[list]) * 256 + (slot & 31) * 8 + (slot >> 5);   // position in the list's query list
     const bool used = ls < lq_cnt[list];
     int q = -1, p = 0;
     if (used) {
@@ -216,7 +228,7 @@ struct Ivf2Workspace {
     int32_t* lq_cnt; int32_t* lq_list; int32_t* qbase; int32_t* item_off_old; int32_t* work_counter;
     int32_t* cnt; float* cand_scores; int32_t* cand_idx;
     // two-stage inverted lists
-    int32_t* blk_off; int32_t* blk_list; int32_t* blk_row0; int32_t* blk_stride; int32_t* item_off; int32_t* sitem_off; int32_t* nblk;
+    int32_t* blk_off; int32_t* blk_list; int32_t* blk_row0; int32_t* blk_stride; int32_t* blk_nq; int32_t* item_off; int32_t* sitem_off; int32_t* nblk;
     int32_t* slotq; int32_t* qslot; uint32_t* thr; float* gmax; uint16_t* qhat; float4* rowc;
     float* eq_slot; float* eq_q;
     int cap; int qp; int64_t bytes;
@@ -250,6 +262,7 @@ static Ivf2Workspace carve_ivf2(void* base, int64_t Npad, int64_t nq, int k) {
     w.blk_list = reinterpret_cast<int32_t*>(take(IVF2_MAXBLK * 4));
     w.blk_row0 = reinterpret_cast<int32_t*>(take(IVF2_MAXBLK * 4));
     w.blk_stride = reinterpret_cast<int32_t*>(take(IVF2_MAXBLK * 4));
+    w.blk_nq = reinterpret_cast<int32_t*>(take(IVF2_MAXBLK * 4));
     w.item_off = reinterpret_cast<int32_t*>(take((IVF2_MAXBLK + 1) * 4));
     w.sitem_off = reinterpret_cast<int32_t*>(take((IVF2_MAXBLK + 1) * 4));
     w.nblk = reinterpret_cast<int32_t*>(take(256));
