@@ -54,10 +54,11 @@ constexpr int CS_THREADS = 256;           // 4 waves (one per SIMD, 512 register
 constexpr int CS_QB = 4;                 // 16-query MFMA column blocks per wave
 constexpr int CS_ROWS = 16;              // bank rows per tile
 constexpr int CS_SLOTS = 3;
-#ifndef CS_PF_SPARSE
-#define CS_PF_SPARSE 6                  // LDS read-ahead (k-steps) of the one-column-block tile loop
-#endif
-constexpr int CS_AUX_BYTES = 1024;       // per slot: row constants (64 lanes x 16 B, first 16 used)
+constexpr int IVF2_MAXBLK_C = 320;       // = IVF2_MAXBLK (aura_knn_ivf2.inl; checked there): blocks of one inverted-list pass at most
+// bf16-row 8-wave kernels (not the probe-mask form, whose masks need the LDS) allocate twice the ring:
+// their row-split form (blocks of at most 128 queries) streams two 16-row tiles per step
+template <bool SRC16, bool MASKED, int NW> constexpr int cs_lds_slots() { return (SRC16 && NW == 8 && !MASKED) ? 2 * CS_SLOTS : CS_SLOTS; }
+constexpr int CS_AUX_BYTES = 256;        // per slot: row constants (16 rows x 16 B, one 4-byte LDS-DMA per lane)
 constexpr int CS_BUF = 1024;             // candidate entries buffered per workgroup (two halves of 512)
 constexpr int CS_FLUSH_MIN = 128;        // a stable half is written out once it holds this many
 constexpr int CS_MODE_SAMPLE = 0, CS_MODE_FILTER = 1;
@@ -454,6 +455,8 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
     constexpr int SLOT_BYTES = TILE_BYTES + CS_AUX_BYTES;
     constexpr int NP = SRC16 ? KS / NW : KS / 2;           // bank pieces (1 KiB each) per wave and tile
     constexpr int GL = NP + 1;                             // global_load_lds per wave and tile
+    constexpr bool SP32 = SRC16 && NW == 8 && !MASKED;     // has the row-split form (see run_segment)
+    constexpr int LSLOTS = cs_lds_slots<SRC16, MASKED, NW>();   // 16-row slots in LDS
     constexpr int NSLOT = CS_SLOTS;                        // ring slots
     extern __shared__ __attribute__((aligned(16))) char csmem[];
     // candidate buffer [NW][2][WCAP][3] follows the slots (addressed through buf_addr)
@@ -529,9 +532,9 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
             }
         }
         if (wave == 0) {   // row constants: one piece per tile, from wave 0 (its vmcnt waits count one more)
-            int64_t row = r0 + (lane & 15);
+            int64_t row = r0 + (lane >> 2);                // 16 rows x 16 B: lane l carries dword l & 3 of row l >> 2
             if (row >= a.N) row = a.N - 1;
-            glds16(reinterpret_cast<const float*>(a.rowc + row), csmem + slot * SLOT_BYTES + TILE_BYTES);
+            glds4(reinterpret_cast<const float*>(a.rowc + row) + (lane & 3), csmem + slot * SLOT_BYTES + TILE_BYTES);
         }
     };
 
@@ -543,7 +546,7 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
     constexpr int EPL = WCAP / 64;                         // entries per lane and half in a write-out
     constexpr int WFLUSH = WCAP / CS_WFLUSH_DIV;
     const uint32_t cs_base = lds_addr(csmem);
-    const uint32_t buf_addr = cs_base + NSLOT * SLOT_BYTES;
+    const uint32_t buf_addr = cs_base + LSLOTS * SLOT_BYTES;
     const uint32_t wreg_addr = buf_addr + wave * (2 * WCAP * 12);
     const uint32_t mask_addr = buf_addr + CS_BUF * 12;            // [256][8] probe masks (MASKED) / [256] slot -> query (IVF)
     // [256] query parts of the error bound (SRC16), signed for the mode: kept in LDS, not in registers --
@@ -589,13 +592,17 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
             // scan; 1 otherwise).  Tile j of block B belongs to the workgroup whose span holds
             // item_off[B] + j * weight.
             int blo;
-            if (blk_cur < 0) {                              // block B with item_off[B] <= c < item_off[B+1]
-                int bhi = ivf_nblk;
-                blo = 0;
-                while (bhi - blo > 1) {
-                    const int mid = (blo + bhi) >> 1;
-                    if ((int64_t)a.item_off[mid] <= c) blo = mid; else bhi = mid;
+            if (blk_cur < 0) {                              // block B with item_off[B] <= c < item_off[B+1]:
+                // B = number of prefixes item_off[1 .. nblk-1] that are <= c (the prefixes never decrease);
+                // five loads in flight and five ballots instead of a chain of nine dependent loads
+                int n_le = 0;
+#pragma unroll
+                for (int i = 0; i < (IVF2_MAXBLK_C + 63) / 64; ++i) {
+                    const int idx = i * 64 + lane;
+                    const bool le = idx >= 1 && idx < ivf_nblk && (int64_t)a.item_off[idx] <= c;
+                    n_le += (int)__popcll(__ballot(le));
                 }
+                blo = __builtin_amdgcn_readfirstlane(n_le);
             } else {
                 blo = blk_cur + 1;                          // the previous segment ran to the end of its block
             }
@@ -615,25 +622,23 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
             seg = (hi - c) < (a.n_tiles - j0) ? (hi - c) : (a.n_tiles - j0);
             c += seg;
         }
-        const int qoff = (int)qblk * 256 + wave * (16 * QB);   // this wave's first query (IVF: block slot)
-        // Query slots in use in this block.  The interval between two tile barriers is ONE wave's serial
-        // work on a tile (DMA issue, MFMAs, epilogue), so the work of a sparse block must be spread over
-        // the waves, not packed into the first ones: the inverted-list prep deals a block's queries
-        // round-robin (query i -> wave i % 8, position i / 8; exact recall: natural order), and a block of
-        // at most 128 queries -- the common case at 8 probes of 256 lists -- runs the ONE-column-block
-        // form of the tile loop (run_segment<1>: 24 instead of 48 MFMAs and half the epilogue per wave
-        // and tile, the second block's fragment registers go to a deeper LDS read-ahead).  Waves without
-        // a query skip MFMAs and epilogue; they still issue their share of the LDS-DMA and meet the barrier.
+        // Query slots in use in this block.  The interval between two barriers is ONE wave's serial work
+        // on a tile (DMA issue, MFMAs, epilogue), and a block of at most 128 queries -- the common case at 8
+        // probes of 256 lists -- leaves half the waves without a query.  Such a block runs the ROW-SPLIT
+        // form of the loop (run_segment<.., 2>): a step streams TWO 16-row tiles (the ring holds 3 x 2
+        // slots), waves w and w + 4 hold the same 32 query slots, and wave w + 4 works on the second tile.
+        // One barrier, one wait and one round of DMA issue then serve 32 rows, and twice the bytes are in
+        // flight per CU.  Waves without a query (or, in an odd last step, without a tile) skip MFMAs and
+        // epilogue; they still issue their share of the LDS-DMA and meet the barrier.
         const int n_used = IVF ? a.blk_nq[qblk] : (a.nq - (int)qblk * 256);
-        if (IVF && MODE == CS_MODE_FILTER) {                // slot -> query table of this block -> LDS
-            int32_t* const s_sq = reinterpret_cast<int32_t*>(csmem + NSLOT * SLOT_BYTES + CS_BUF * 12);
-            if (tid < 256) s_sq[tid] = a.slotq[qblk * 256 + tid];
-            __syncthreads();
-        }
 
-        auto run_segment = [&](auto NB_) {
-        constexpr int NBc = decltype(NB_)::value;           // column blocks (16 queries) per wave: QB, or 1 (sparse block)
-        int my_cnt = (IVF && NW == 8) ? (n_used - wave + 7) / 8 : n_used - wave * (16 * QB);
+        auto run_segment = [&](auto NB_, auto RS_) {
+        constexpr int NBc = decltype(NB_)::value;           // column blocks (16 queries) per wave
+        constexpr int RS = decltype(RS_)::value;            // 16-row tiles per step (2: row-split form)
+        const int qg = RS == 2 ? (wave & 3) : wave;         // query group: slots [qg * 16 QB, + 16 QB) of the block
+        const int rh = RS == 2 ? (wave >> 2) : 0;           // which tile of the step this wave works on
+        const int qoff = (int)qblk * 256 + qg * (16 * QB);  // this wave's first query (IVF: block slot)
+        int my_cnt = n_used - qg * (16 * QB);
         my_cnt = my_cnt < 0 ? 0 : (my_cnt > 16 * NBc ? 16 * NBc : my_cnt);
         // column blocks this wave runs (wave-uniform, in a scalar register)
         const int nb = __builtin_amdgcn_readfirstlane(NBc == 2 ? (my_cnt + 15) / 16 : (my_cnt > 0 ? NBc : 0));
@@ -643,8 +648,9 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
         // their final registers
         bf16x8v qf[NBc][KS];
         float thrf[NBc];
+        int qid[NBc];                                       // IVF filter: the queries in this lane's slots (16 b + lr)
         if (MASKED) {                                       // this block's probe masks -> LDS
-            uint32_t* const s_mask = reinterpret_cast<uint32_t*>(csmem + NSLOT * SLOT_BYTES + CS_BUF * 12);
+            uint32_t* const s_mask = reinterpret_cast<uint32_t*>(csmem + LSLOTS * SLOT_BYTES + CS_BUF * 12);
             for (int i = tid; i < 256 * 8; i += THREADS) {
                 const int64_t q = qblk * 256 + (i >> 3);
                 s_mask[i] = q < a.nq ? a.probe_mask[q * 8 + (i & 7)] : 0u;
@@ -653,7 +659,7 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
         }
         // query part of the error bound: the accumulators start at +eq (FILTER: U) / -eq (SAMPLE: L)
         if (SRC16) {
-            float* const s_eq = reinterpret_cast<float*>(csmem + NSLOT * SLOT_BYTES + EQ_OFF);
+            float* const s_eq = reinterpret_cast<float*>(csmem + LSLOTS * SLOT_BYTES + EQ_OFF);
             if (tid < 256) {
                 const int64_t q = qblk * 256 + tid;
                 const float v = a.eq[q < a.nq ? q : a.nq - 1];
@@ -670,21 +676,41 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
             }
 #pragma unroll
             for (int b = 0; b < NBc; ++b) thrf[b] = qoff + 16 * b + lr < a.nq ? ord_unkey(key[b]) : INFINITY;
+#pragma unroll
+            for (int b = 0; b < NBc; ++b) qid[b] = IVF ? a.slotq[qoff + 16 * b + lr] : 0;
         } else {
 #pragma unroll
             for (int b = 0; b < NBc; ++b) thrf[b] = INFINITY;
         }
 #pragma unroll
-        for (int b = 0; b < NBc; ++b) {
-            const uint16_t* qp = a.qhat + (((qblk * 16 + wave * QB + b) * KS) * 64 + lane) * 8;
+        for (int b = 0; b < NBc; ++b) {                     // (a column block without a query is never multiplied)
+            const uint16_t* qp = a.qhat + (((qblk * 16 + qg * QB + b) * KS) * 64 + lane) * 8;
+            if (b < nb || NBc != 2) {
 #pragma unroll
-            for (int s = 0; s < KS; ++s)
-                qf[b][s] = *reinterpret_cast<const bf16x8v*>(qp + (int64_t)s * 512);
+                for (int s = 0; s < KS; ++s)
+                    qf[b][s] = *reinterpret_cast<const bf16x8v*>(qp + (int64_t)s * 512);
+            } else {
+#pragma unroll
+                for (int s = 0; s < KS; ++s)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) qf[b][s][e] = 0;
+            }
         }
         // the first two tiles start streaming while the fragments are still in flight: the single
         // wait in front of the first pin below then covers fragments and tiles alike
-        issue(j0, 0);
-        if (seg > 1) issue(j0 + 1, 1);
+        // step T of the segment = tile j0 + T (RS 1) / tiles j0 + 2T and j0 + 2T + 1 (RS 2; an odd last
+        // step streams its one tile twice, so that every step has the same number of pieces in flight)
+        const int64_t n_steps = RS == 2 ? (seg + 1) / 2 : seg;
+        auto issue_step = [&](int64_t T, int ss) {
+            if (RS == 2) {
+                issue(j0 + 2 * T, 2 * ss);
+                issue(j0 + (2 * T + 1 < seg ? 2 * T + 1 : seg - 1), 2 * ss + 1);
+            } else {
+                issue(j0 + T, ss);
+            }
+        };
+        issue_step(0, 0);
+        if (n_steps > 1) issue_step(1, 1);
 #pragma unroll
         for (int b = 0; b < NBc; ++b) {
 #pragma unroll
@@ -703,7 +729,7 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
         f32x4v acc[NBc];
         f32x4v rcv[4];                                       // constants of rows 4 lg .. 4 lg + 3
         int slot = 0;
-        const int64_t n_int = seg;
+        const int64_t n_int = n_steps;
         // AURA_CS_DBG bit 64: per-wave phase times (100 MHz ticks) into a.gmax (FILTER launches only)
         const bool tm = MODE == CS_MODE_FILTER && (a.dbg & 64) && a.gmax != nullptr;
         uint32_t tacc[6] = {0u, 0u, 0u, 0u, 0u, 0u};       // wait+barrier, check+issue, -, mma, write-out, epi
@@ -712,9 +738,9 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
             const uint32_t ts0 = stamp();
             // this tile's pieces have landed; the next tile's (NP per wave, + the row constants on wave 0)
             // stay in flight
-            if (t + 1 >= seg) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            else if (wave == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(GL) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NP) : "memory");
+            if (t + 1 >= n_steps) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            else if (wave == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(RS * GL) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(RS * NP) : "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             const uint32_t ts1 = stamp();
@@ -724,7 +750,7 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
             if (SRC16) {
                 uint32_t ln2 = (uint32_t)lane;
                 asm volatile("" : "+v"(ln2));                // recomputed per tile (see issue())
-                const uint32_t ea = eq_addr + (uint32_t)(wave * (16 * QB)) * 4u + (ln2 & 15u) * 4u;
+                const uint32_t ea = eq_addr + (uint32_t)(qg * (16 * QB)) * 4u + (ln2 & 15u) * 4u;
 #pragma unroll
                 for (int b = 0; b < NBc; ++b)
                     asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(eqr[b]) : "v"(ea), "n"(64 * b) : "memory");
@@ -746,7 +772,10 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
                                            fl_pos1);
                 }
             }
-            if (t + 2 < seg && !(a.dbg & 4)) issue(j0 + t + 2, (slot + 2) % NSLOT);
+            if (t + 2 < n_steps && !(a.dbg & 4)) issue_step(t + 2, (slot + 2) % NSLOT);
+            const int cslot = RS == 2 ? 2 * slot + rh : slot;       // the 16-row slot this wave computes on
+            const int64_t ctile = RS == 2 ? 2 * t + rh : t;         // ... = tile j0 + ctile of the block
+            const bool work = wave_active && ctile < seg;
 
             auto mma = [&]() {
             if (SRC16) {
@@ -760,14 +789,12 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
                 for (int e = 0; e < 4; ++e) acc[b][e] = SRC16 ? __uint_as_float(eqr[b]) : 0.0f;
             // fragment reads run two k-steps ahead of the MFMAs (one wave per SIMD: nothing else
             // hides the LDS latency)
-            // k-steps the reads run ahead (8 waves: registers are short, the other wave hides the latency;
-            // the one-column-block form has the second block's registers to spend and half the MFMA time
-            // per step to hide the LDS latency behind)
-            constexpr int PF = (SRC16 && NW == 4) ? CS_PF16 : (NBc < QB ? CS_PF_SPARSE : 2);
+            // k-steps the reads run ahead (8 waves: registers are short, the other wave hides the latency)
+            constexpr int PF = (SRC16 && NW == 4) ? CS_PF16 : 2;
             f32x4v xr[PF + 1][2];
             constexpr int RP = SRC16 ? 1 : 2;                // LDS reads per k-step
             constexpr int S_RC = KS >= 3 ? KS - 3 : 0;       // the row constants are fetched behind this step
-            const uint32_t a0 = cs_base + slot * SLOT_BYTES + off0, a1 = cs_base + slot * SLOT_BYTES + off1;
+            const uint32_t a0 = cs_base + cslot * SLOT_BYTES + off0, a1 = cs_base + cslot * SLOT_BYTES + off1;
             if (!(a.dbg & 1)) {
             cs_static_for<0, (PF < KS ? PF : KS)>([&](auto S) {
                 constexpr int s = decltype(S)::value;
@@ -799,20 +826,19 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
                 }
                 cs_static_for<0, NBc>([&](auto Bc) {
                     constexpr int b = decltype(Bc)::value;
-                    // exact recall, last query block: the second column block of a wave runs only when it
-                    // holds a query (the skip is a scalar branch inside the statement, so the accumulators
-                    // keep one definition)
-                    constexpr bool CND = !IVF && NBc == 2 && b == 1;
+                    // the second column block of a wave runs only when it holds a query (the skip is a
+                    // scalar branch inside the statement, so the accumulators keep one definition)
+                    constexpr bool CND = NBc == 2 && b == 1;
                     constexpr bool INA = b * KS + s < QA;
                     mfma_bf16_q<INA, s == KS - 1, !SRC16, CND>(acc[b], af, qf[b][s], nb - 1);
                 });
                 // the epilogue's row constants are fetched behind the last two k-steps
                 if constexpr (s == S_RC)
-                    lds_read4x16_nowait(cs_base + slot * SLOT_BYTES + TILE_BYTES + lg * 64, rcv[0], rcv[1], rcv[2], rcv[3]);
+                    lds_read4x16_nowait(cs_base + cslot * SLOT_BYTES + TILE_BYTES + lg * 64, rcv[0], rcv[1], rcv[2], rcv[3]);
                 __builtin_amdgcn_sched_barrier(0);
             });
             } else {
-                lds_read4x16_nowait(cs_base + slot * SLOT_BYTES + TILE_BYTES + lg * 64, rcv[0], rcv[1], rcv[2], rcv[3]);
+                lds_read4x16_nowait(cs_base + cslot * SLOT_BYTES + TILE_BYTES + lg * 64, rcv[0], rcv[1], rcv[2], rcv[3]);
             }
             lds_wait4(rcv[0], rcv[1], rcv[2], rcv[3]);
             __builtin_amdgcn_sched_barrier(0);
@@ -839,7 +865,7 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
 #pragma unroll
                     for (int b = 0; b < QB; ++b)
                         asm volatile("ds_read_b32 %0, %1" : "=v"(mw[b * 4 + e])
-                                     : "v"(mask_addr + (uint32_t)((wave * (16 * QB) + 16 * b + lr) * 32 + ((cidv[e] < 0 ? 0 : cidv[e]) >> 5) * 4))
+                                     : "v"(mask_addr + (uint32_t)((qg * (16 * QB) + 16 * b + lr) * 32 + ((cidv[e] < 0 ? 0 : cidv[e]) >> 5) * 4))
                                      : "memory");
                 }
                 if constexpr (QB == 4)
@@ -913,7 +939,9 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
                         int q = qoff + 16 * (idx >> 2) + lr;
                         int row = (int)r0 + 4 * lg + (idx & 3);
                         if (IVF) {                           // slot -> query, sorted row -> bank row
-                            q = lds_read_i32(mask_addr + (uint32_t)((q & 255) * 4));
+                            q = qid[0];
+#pragma unroll
+                            for (int b = 1; b < NBc; ++b) q = (idx >> 2) == b ? qid[b] : q;
                             float rb = rcv[0][3];
                             rb = (idx & 3) == 1 ? rcv[1][3] : rb;
                             rb = (idx & 3) == 2 ? rcv[2][3] : rb;
@@ -939,12 +967,12 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
             };
             const uint32_t ts2 = stamp();
             const uint32_t ts3 = ts2;
-            if (wave_active) mma();
+            if (work) mma();
             const uint32_t ts4 = stamp();
             if (MODE == CS_MODE_FILTER && fl_n > 0) {       // second step of the write-out (wave-uniform)
-                if (t + 2 >= seg) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                else if (wave == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GL) : "memory");   // reservations are older
-                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+                if (t + 2 >= n_steps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (wave == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RS * GL) : "memory");   // reservations are older
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RS * NP) : "memory");
                 const uint32_t eb = wreg_addr + (par ^ 1) * (WCAP * 12);
 #pragma unroll
                 for (int u = 0; u < EPL; ++u) {
@@ -961,7 +989,7 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
             }
 
             const uint32_t ts5 = stamp();
-            if (wave_active) epi(t);
+            if (work) epi(ctile);
             if (tm) {
                 const uint32_t ts6 = stamp();
                 tacc[0] += ts1 - ts0; tacc[1] += ts2 - ts1; tacc[2] += ts3 - ts2;
@@ -976,15 +1004,17 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
             o[6] += (float)seg;
         }
         };
-        if (IVF && NW == 8 && QB == 2 && n_used <= 128 && !(a.dbg & 256)) run_segment(std::integral_constant<int, 1>{});
-        else run_segment(std::integral_constant<int, QB>{});
+        if (SP32 && QB == 2 && n_used <= 128 && !(a.dbg & 256)) run_segment(std::integral_constant<int, QB>{}, std::integral_constant<int, 2>{});
+        else run_segment(std::integral_constant<int, QB>{}, std::integral_constant<int, 1>{});
+        // segment end: the stream has drained and every wave is done with the block's LDS tables.  Buffered
+        // candidates carry their query and bank row, so they stay where they are until the buffer fills or
+        // the workgroup's span ends.
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (MODE == CS_MODE_FILTER) {                       // span end: both halves go out
-            if (wc[0] > 0 || wc[1] > 0) flush_all();
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-        }
+    }
+    if (MODE == CS_MODE_FILTER) {                           // span end: both halves go out
+        if (wc[0] > 0 || wc[1] > 0) flush_all();
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }
     if (MODE == CS_MODE_FILTER && (a.dbg & 64) && a.gmax != nullptr && lane == 0)   // whole-kernel time of this wave
         a.gmax[((int64_t)blockIdx.x * 8 + wave) * 8 + 7] += (float)((uint32_t)__builtin_amdgcn_s_memrealtime() - t_kernel0);
@@ -1231,7 +1261,7 @@ inline bool coarse_eligible(const float* bank, const uint16_t* bank16, const flo
 
 template <int KS, bool SRC16, bool MASKED, int NW = 4>
 inline int launch_coarse(const CoarseArgs& a, int mode, int grid, hipStream_t s) {
-    const size_t lds = (size_t)CS_SLOTS * (KS * (SRC16 ? 1024 : 2048) + CS_AUX_BYTES) + (size_t)CS_BUF * 12 +
+    const size_t lds = (size_t)cs_lds_slots<SRC16, MASKED, NW>() * (KS * (SRC16 ? 1024 : 2048) + CS_AUX_BYTES) + (size_t)CS_BUF * 12 +
                        (MASKED ? 256 * 32 : 0) + (SRC16 ? 256 * 4 : 0);
     if (ensure_lds_attr(reinterpret_cast<const void*>(coarse_scan_kernel<KS, CS_MODE_SAMPLE, SRC16, MASKED, false, NW>), (int)lds) ||
         ensure_lds_attr(reinterpret_cast<const void*>(coarse_scan_kernel<KS, CS_MODE_FILTER, SRC16, MASKED, false, NW>), (int)lds))

@@ -22,6 +22,7 @@
 
 constexpr int IVF2_STILES = 32;            // sample tiles (of 16 rows) per list
 constexpr int IVF2_MAXBLK = 256 + IVF_MAXQ * 8 / 256;   // blocks of one pass at most
+static_assert(IVF2_MAXBLK == IVF2_MAXBLK_C, "coarse_scan_kernel's block search covers IVF2_MAXBLK_C prefixes");
 
 // ---- plan: blocks, their row ranges and the work-item prefixes (one workgroup) ----
 __global__ __launch_bounds__(256) void ivf2_plan_kernel(const int32_t* __restrict__ lq_cnt,
@@ -123,10 +124,7 @@ __global__ __launch_bounds__(256) void ivf2_prep_kernel(const float* __restrict_
     const int B = (int)(vs >> 8);
     if (B >= nblk[0]) return;
     const int list = blk_list[B];
-    // slot = wave * 32 + position: a block's queries are dealt round-robin over the scan's 8 waves (query
-    // i of the block -> wave i % 8, position i / 8), see coarse_scan_kernel
-    const int slot = (int)(vs & 255);
-    const int ls = (B - blk_off[list]) * 256 + (slot & 31) * 8 + (slot >> 5);   // position in the list's query list
+    const int ls = (B - blk_off[list]) * 256 + (int)(vs & 255);           // slot inside the list's query list
     const bool used = ls < lq_cnt[list];
     int q = -1, p = 0;
     if (used) {
@@ -280,7 +278,7 @@ static Ivf2Workspace carve_ivf2(void* base, int64_t Npad, int64_t nq, int k) {
 
 template <int KS, int NW>
 inline int launch_coarse_ivf(const CoarseArgs& a, int mode, int grid, hipStream_t s) {
-    const size_t lds = (size_t)CS_SLOTS * (KS * 1024 + CS_AUX_BYTES) + (size_t)CS_BUF * 12 + 256 * 4 + 256 * 4;
+    const size_t lds = (size_t)cs_lds_slots<true, false, NW>() * (KS * 1024 + CS_AUX_BYTES) + (size_t)CS_BUF * 12 + 256 * 4 + 256 * 4;
     if (ensure_lds_attr(reinterpret_cast<const void*>(coarse_scan_kernel<KS, CS_MODE_SAMPLE, true, false, true, NW>), (int)lds) ||
         ensure_lds_attr(reinterpret_cast<const void*>(coarse_scan_kernel<KS, CS_MODE_FILTER, true, false, true, NW>), (int)lds))
         return AURA_E_LAUNCH;
