@@ -2136,8 +2136,8 @@ int aura_knn_search_ivf2(const float* bank, const float* inv_norm, const float* 
     // AURA_IVF_W=s,d overrides (tuning runs); the one-wave-per-SIMD form has a single tile loop.
     static int w_sparse = 0, w_dense = 0;
     if (w_sparse == 0) {
-        int ws = 3, wd = 4;
-        if (const char* e = getenv("AURA_IVF_W")) { if (sscanf(e, "%d,%d", &ws, &wd) != 2 || ws < 1 || wd < 1 || ws > 64 || wd > 64) { ws = 3; wd = 4; } }
+        int ws = 2, wd = 3;
+        if (const char* e = getenv("AURA_IVF_W")) { if (sscanf(e, "%d,%d", &ws, &wd) != 2 || ws < 1 || wd < 1 || ws > 64 || wd > 64) { ws = 2; wd = 3; } }
         if (w4) ws = wd = 1;
         w_dense = wd; w_sparse = ws;
     }
