@@ -131,7 +131,7 @@ __device__ __forceinline__ void glds4(const float* g, char* lds_wave_base) {
 constexpr int CS_PF16 = AURA_CS_PF16;       // bf16-row kernels: fragment reads run this many k-steps ahead
 constexpr int CS_QA8 = 30;  // 8-wave kernels (48 fragments, 8 accumulators per wave)
 #ifndef AURA_CS_WFLUSH_DIV
-#define AURA_CS_WFLUSH_DIV 4
+#define AURA_CS_WFLUSH_DIV 2
 #endif
 constexpr int CS_WFLUSH_DIV = AURA_CS_WFLUSH_DIV;   // a wave writes a stable half out once it holds capacity / this
 constexpr int CS_QA = 60;   // fragments (4 registers each) kept in AGPRs, next to the 16 accumulators
