@@ -1728,10 +1728,15 @@ inline int run_coarse_pass(const float* bank, const uint16_t* bank16, const floa
     if (sample_rows < floor_rows) sample_rows = floor_rows;
     const int64_t ntiles128 = N / 128;                       // whole logical tiles only
     int64_t n_sample = (sample_rows + 127) / 128;
-    if (n_sample * 8 > THR_MAX_GROUPS) n_sample = THR_MAX_GROUPS / 8;
+    // a group is a 16-row tile while the sample fits THR_MAX_GROUPS of them (banks up to ~1 M rows at
+    // k = 32); beyond, a whole 128-row logical tile -- the k-th largest group maximum certifies k
+    // distinct rows either way, and the sample keeps growing with the bank (up to 512 K rows) instead of
+    // stopping at 64 K, where a 10 M-row bank's queries collected more candidates than the refine stage holds
+    const int gshift = n_sample * 8 > THR_MAX_GROUPS ? 3 : 0;
+    if (gshift && n_sample > THR_MAX_GROUPS) n_sample = THR_MAX_GROUPS;
     if (n_sample > ntiles128) n_sample = ntiles128;
     const int tile_step = (int)(ntiles128 / n_sample);
-    const int G = (int)n_sample * 8;
+    const int G = gshift ? (int)n_sample : (int)n_sample * 8;
     if (G < k) return AURA_E_INVAL;                          // ruled out by coarse_eligible()
 
     // per-call preparation: bf16 query fragments + 1/||q|| (+ overflow-flag reset), row constants
@@ -1759,17 +1764,18 @@ inline int run_coarse_pass(const float* bank, const uint16_t* bank16, const floa
     c.cap = w.cap; c.probe_mask = probe_mask;
     const int cus = device_cu_count();
 
-    c.n_tiles = G; c.tile_step = tile_step; c.n_sample = (int)n_sample;
-    c.gmax = w.gmax; c.gmax_ld = THR_MAX_GROUPS;
+    c.n_tiles = n_sample * 8; c.tile_step = tile_step; c.n_sample = (int)n_sample;
+    c.gmax = w.gmax; c.gmax_ld = THR_MAX_GROUPS; c.gshift = gshift;
+    if (gshift && hipMemsetAsync(w.gmax, 0, (size_t)nqb * THR_MAX_GROUPS * 4, s) != hipSuccess) return AURA_E_LAUNCH;
     {
-        const int64_t items = (int64_t)G * ((nqb + 255) / 256);
+        const int64_t items = (int64_t)n_sample * 8 * ((nqb + 255) / 256);
         if ((rc = dispatch_coarse(c, CS_MODE_SAMPLE, (int)(items < cus ? items : cus), s))) return rc;
     }
     {
         const dim3 tg((unsigned)((nqb + 3) / 4)), tb(256);
 #define AURA_THR(PER)                                                                              \
     hipLaunchKernelGGL((coarse_threshold_kernel<PER>), tg, tb, 0, s, w.gmax, (int64_t)THR_MAX_GROUPS, \
-                       G, k, nqb, w.thr, w.cnt)
+                       G, k, nqb, gshift ? 1 : 0, w.thr, w.cnt)
         if (G <= 512) AURA_THR(8);
         else if (G <= 1024) AURA_THR(16);
         else if (G <= 2048) AURA_THR(32);
@@ -1778,7 +1784,7 @@ inline int run_coarse_pass(const float* bank, const uint16_t* bank16, const floa
     }
     if ((rc = check_launch())) return rc;
 
-    c.n_tiles = (N + CS_ROWS - 1) / CS_ROWS; c.gmax = nullptr;
+    c.n_tiles = (N + CS_ROWS - 1) / CS_ROWS; c.gmax = nullptr; c.gshift = 0;
     static int tm_left = 3;                                  // AURA_CS_DBG bit 64: phase times of the first launches
     const bool tm = (cs_dbg & 64) && tm_left > 0;
     if (tm) {
@@ -2130,6 +2136,7 @@ int aura_knn_search_ivf2(const float* bank, const float* inv_norm, const float* 
             fflush(stderr);
         }
     };
+    const int stiles = ivf2_stiles(n_sorted);                // sample tiles per list
     static const bool w4 = getenv("AURA_CS_WAVES4") != nullptr;   // A/B runs: one wave per SIMD
     // Relative time of a filter tile in a block of <= 128 queries and in a fuller one (the one- and the
     // two-column-block form of the tile loop): the plan splits tiles x weight evenly over the workgroups.
@@ -2154,7 +2161,7 @@ int aura_knn_search_ivf2(const float* bank, const float* inv_norm, const float* 
         stage("prepare");
         hipLaunchKernelGGL(ivf2_plan_kernel, dim3(1), dim3(256), 0, s, w.lq_cnt, pad_off, list_len, w.blk_off,
                            w.blk_list, w.blk_row0, w.blk_stride, w.blk_nq, w.item_off, w.sitem_off, w.nblk,
-                           w_sparse, w_dense);
+                           stiles, w_sparse, w_dense);
         if ((rc = check_launch())) return rc;
         stage("plan");
         const int qblocks = IVF2_MAXBLK * 256 / 4;
@@ -2172,7 +2179,7 @@ int aura_knn_search_ivf2(const float* bank, const float* inv_norm, const float* 
         c.thr = w.thr; c.cnt = w.cnt; c.cand_scores = w.cand_scores; c.cand_idx = w.cand_idx; c.cap = w.cap;
         c.blk_row0 = w.blk_row0; c.blk_stride = w.blk_stride; c.nblk = w.nblk; c.slotq = w.slotq;
         c.blk_nq = w.blk_nq; c.w_sparse = w_sparse; c.w_dense = w_dense;
-        c.gmax = w.gmax; c.gmax_ld = 2 * IVF2_STILES; c.item_off = w.sitem_off;
+        c.gmax = w.gmax; c.gmax_ld = 2 * stiles; c.item_off = w.sitem_off;
         static const int cs_dbg = getenv("AURA_CS_DBG") ? atoi(getenv("AURA_CS_DBG")) : 0;
         c.dbg = cs_dbg;
         auto launch = [&](int mode) -> int {
@@ -2187,8 +2194,16 @@ int aura_knn_search_ivf2(const float* bank, const float* inv_norm, const float* 
         };
         if ((rc = launch(CS_MODE_SAMPLE))) return rc;
         stage("sample scan");
-        hipLaunchKernelGGL(ivf2_threshold_kernel, dim3((unsigned)((nqb + 3) / 4)), dim3(256), 0, s, w.gmax,
-                           w.qslot, w.blk_list, list_len, nprobe, k, nqb, w.thr, w.cnt);
+        {
+            const dim3 tg((unsigned)((nqb + 3) / 4)), tb(256);
+#define AURA_THR2(PER) hipLaunchKernelGGL((ivf2_threshold_kernel<PER>), tg, tb, 0, s, w.gmax, w.qslot, w.blk_list, list_len, \
+                                          nprobe, k, nqb, w.thr, w.cnt)
+            if (stiles == 32) AURA_THR2(8);
+            else if (stiles == 64) AURA_THR2(16);
+            else if (stiles == 128) AURA_THR2(32);
+            else AURA_THR2(64);
+#undef AURA_THR2
+        }
         if ((rc = check_launch())) return rc;
         stage("threshold");
         c.gmax = nullptr; c.item_off = w.item_off;

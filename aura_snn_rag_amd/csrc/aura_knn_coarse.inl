@@ -84,8 +84,10 @@ struct CoarseArgs {
     int nq;
     int64_t n_tiles;         // 16-row tiles this launch walks (per 256-query block)
     int tile_step, n_sample; // SAMPLE: tile j -> logical 128-row tile (j/8)*tile_step, sub-tile j%8
-    float* gmax;             // SAMPLE out: [nq][gmax_ld], group = tile j
+    float* gmax;             // SAMPLE out: [nq][gmax_ld], group = tile j >> gshift
     int64_t gmax_ld;
+    int gshift;              // full scan, large banks: 3 = a group is a whole 128-row logical tile; the eight 16-row
+                             // tiles max-combine their ORDERED KEYS (atomic, gmax zeroed by the caller)
     const uint32_t* thr;     // FILTER in: [nq] ordered keys
     int32_t* cnt;            // [nq][CNT_STRIDE]
     float* cand_scores;      // [nq][cap]: U
@@ -408,7 +410,7 @@ __global__ __launch_bounds__(256) void coarse_prep_kernel(const float* __restric
 // the candidate counters.
 template <int PER>
 __global__ __launch_bounds__(256) void coarse_threshold_kernel(const float* __restrict__ gmax,
-                                                               int64_t gmax_ld, int G, int k, int nq,
+                                                               int64_t gmax_ld, int G, int k, int nq, int keys,   // keys: gmax holds ordered keys
                                                                uint32_t* __restrict__ thr_out,
                                                                int32_t* __restrict__ cnt_out) {
     const int lane = threadIdx.x & 63;
@@ -418,7 +420,8 @@ __global__ __launch_bounds__(256) void coarse_threshold_kernel(const float* __re
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const int g = i * 64 + lane;
-        key[i] = g < G ? ord_key(gmax[(int64_t)q * gmax_ld + g]) : 0u;
+        const float v = g < G ? gmax[(int64_t)q * gmax_ld + g] : 0.0f;
+        key[i] = g < G ? (keys ? __float_as_uint(v) : ord_key(v)) : 0u;
     }
     uint32_t T = 0u;
     for (int bit = 31; bit >= 0; --bit) {
@@ -914,7 +917,13 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
                             a.gmax[(int64_t)q * a.gmax_ld + 2 * (j0 + tt) + (lg >> 1)] = mx;
                     } else {
                         mx = fmaxf(mx, __shfl_xor(mx, 32));
-                        if (lg == 0 && q < a.nq) a.gmax[(int64_t)q * a.gmax_ld + (j0 + tt)] = mx;
+                        if (lg == 0 && q < a.nq) {
+                            if (a.gshift)
+                                atomicMax(reinterpret_cast<unsigned int*>(a.gmax) + (int64_t)q * a.gmax_ld + ((j0 + tt) >> a.gshift),
+                                          ord_key(mx));
+                            else
+                                a.gmax[(int64_t)q * a.gmax_ld + (j0 + tt)] = mx;
+                        }
                     }
                 }
             } else if (!(a.dbg & 32)) {

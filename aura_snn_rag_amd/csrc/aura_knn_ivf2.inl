@@ -20,7 +20,18 @@
 // Results are bit-identical to aura_knn_search_ivf and to the masked scans (same candidate sets,
 // same fp32 arithmetic, ties to the lower row).
 
-constexpr int IVF2_STILES = 32;            // sample tiles (of 16 rows) per list
+constexpr int IVF2_STILES = 32;            // sample tiles (of 16 rows) per list, at least
+constexpr int IVF2_STILES_MAX = 256;       // ... and at most
+// Sample tiles per list for a sorted shadow of n_sorted rows: about an eighth of an average list (so that
+// the k-th best of the sample sits near rank 8 k of the probed rows whatever the bank's size -- with a
+// fixed 32 tiles a 10 M-row bank's queries collected more candidates than the refine stage holds and
+// every call fell back to the fp32 lists), a power of two in [32, 256].
+static inline int ivf2_stiles(int64_t n_sorted) {
+    const int64_t avg_tiles = n_sorted / 16 / 256;
+    int st = IVF2_STILES;
+    while (st < IVF2_STILES_MAX && (int64_t)st * 8 < avg_tiles) st *= 2;
+    return st;
+}
 constexpr int IVF2_MAXBLK = 256 + IVF_MAXQ * 8 / 256;   // blocks of one pass at most
 static_assert(IVF2_MAXBLK == IVF2_MAXBLK_C, "coarse_scan_kernel's block search covers IVF2_MAXBLK_C prefixes");
 
@@ -36,6 +47,7 @@ __global__ __launch_bounds__(256) void ivf2_plan_kernel(const int32_t* __restric
                                                         int32_t* item_off,   // [MAXBLK + 1] filter work (tiles x block weight)
                                                         int32_t* sitem_off,  // [MAXBLK + 1] sample items
                                                         int32_t* nblk,
+                                                        int stiles,          // sample tiles per list (ivf2_stiles)
                                                         int w_sparse, int w_dense) {   // cost of a tile of a block of <= 128 / more queries
     __shared__ int s_nb[257];
     const int tid = threadIdx.x;
@@ -56,7 +68,7 @@ __global__ __launch_bounds__(256) void ivf2_plan_kernel(const int32_t* __restric
         blk_row0[b] = pad_off[tid];
         const int left = lq_cnt[tid] - (b - s_nb[tid]) * 256;
         blk_nq[b] = left < 256 ? left : 256;
-        blk_stride[b] = tiles > IVF2_STILES ? tiles / IVF2_STILES : 1;   // sample tiles j * stride, j < 32
+        blk_stride[b] = tiles > stiles ? tiles / stiles : 1;   // sample tiles j * stride, j < stiles
     }
     __syncthreads();
     // work prefixes: list c contributes (tiles of c) x (weights of its blocks) filter work and
@@ -66,7 +78,7 @@ __global__ __launch_bounds__(256) void ivf2_plan_kernel(const int32_t* __restric
     // all but the last block of a list hold 256 queries.
     __shared__ int s_it[257], s_st[257];
     const int nb = s_nb[tid + 1] - s_nb[tid];
-    const int stl = tiles < IVF2_STILES ? tiles : IVF2_STILES;
+    const int stl = tiles < stiles ? tiles : stiles;
     const int last_left = lq_cnt[tid] - (nb - 1) * 256;
     const int w_last = last_left <= 128 ? w_sparse : w_dense;
     s_it[tid + 1] = nb > 0 ? tiles * ((nb - 1) * w_dense + w_last) : 0; s_st[tid + 1] = nb * stl;
@@ -178,7 +190,8 @@ __global__ __launch_bounds__(256) void ivf2_prep_kernel(const float* __restrict_
 }
 
 // ---- thresholds: one wave per query over the group maxima of its nprobe lists' sample tiles ----
-__global__ __launch_bounds__(256) void ivf2_threshold_kernel(const float* __restrict__ gmax,       // [slots][2 STILES]
+template <int PER>                                         // keys per lane = stiles / 4
+__global__ __launch_bounds__(256) void ivf2_threshold_kernel(const float* __restrict__ gmax,       // [slots][2 stiles]
                                                              const int32_t* __restrict__ qslot,    // [nq][8]
                                                              const int32_t* __restrict__ blk_list,
                                                              const int32_t* __restrict__ list_len,
@@ -188,19 +201,22 @@ __global__ __launch_bounds__(256) void ivf2_threshold_kernel(const float* __rest
     const int lane = threadIdx.x & 63;
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= nq) return;
-    // lane -> probe lane>>3, 8-row sample groups 8 (lane&7) .. +7 (two groups per sample tile)
+    // lane -> probe lane>>3, 8-row sample groups PER (lane&7) .. +PER-1 (two groups per sample tile)
+    constexpr int STL = PER * 4;
     const int p = lane >> 3;
-    uint32_t key[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    uint32_t key[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) key[i] = 0u;
     int vs = -1;
     if (p < nprobe) {
         vs = qslot[(int64_t)q * 8 + p];
         const int list = blk_list[vs >> 8];
         const int tiles = (list_len[list] + 15) / 16;
-        const int groups = 2 * (tiles < IVF2_STILES ? tiles : IVF2_STILES);
+        const int groups = 2 * (tiles < STL ? tiles : STL);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int g = 8 * (lane & 7) + i;
-            if (g < groups) key[i] = ord_key(gmax[(int64_t)vs * (2 * IVF2_STILES) + g]);
+        for (int i = 0; i < PER; ++i) {
+            const int g = PER * (lane & 7) + i;
+            if (g < groups) key[i] = ord_key(gmax[(int64_t)vs * (2 * STL) + g]);
         }
     }
     uint32_t T = 0u;
@@ -208,7 +224,7 @@ __global__ __launch_bounds__(256) void ivf2_threshold_kernel(const float* __rest
         const uint32_t cand = T | (1u << bit);
         int c = 0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) c += __popcll(__ballot(key[i] >= cand));
+        for (int i = 0; i < PER; ++i) c += __popcll(__ballot(key[i] >= cand));
         if (c >= k) T = cand;
     }
     // fewer than k sampled groups (short lists): every real candidate row must pass, the padding
@@ -269,7 +285,7 @@ static Ivf2Workspace carve_ivf2(void* base, int64_t Npad, int64_t nq, int k) {
     w.thr = reinterpret_cast<uint32_t*>(take((int64_t)IVF2_MAXBLK * 256 * 4));
     w.eq_slot = reinterpret_cast<float*>(take((int64_t)IVF2_MAXBLK * 256 * 4));
     w.eq_q = reinterpret_cast<float*>(take(qp * 4));
-    w.gmax = reinterpret_cast<float*>(take((int64_t)IVF2_MAXBLK * 256 * 2 * IVF2_STILES * 4));
+    w.gmax = reinterpret_cast<float*>(take((int64_t)IVF2_MAXBLK * 256 * 2 * ivf2_stiles(Npad) * 4));
     w.qhat = reinterpret_cast<uint16_t*>(take((int64_t)IVF2_MAXBLK * 256 * 768 * 2));
     w.rowc = reinterpret_cast<float4*>(take((Npad > 0 ? Npad : 1) * 16));
     w.bytes = off;

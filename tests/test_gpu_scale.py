@@ -210,3 +210,45 @@ def test_sharded_bank_on_hip_kernels_two_ranks_one_gpu(dev, tmp_path):
     for r in range(2):
         s_o, r_o = parts[r]["own"]
         assert torch.equal(r_o, pr_c[r * 350:(r + 1) * 350])
+
+
+def test_large_bank_samples_grow_with_the_bank(dev):
+    """A bank well beyond 1 M rows (6 M x 64 here: 1.5 GB): the prefilter's sample grows with the bank --
+    128-row groups in the full scan, more sample tiles per inverted list -- so the candidate lists stay
+    inside the refine stage's capacity and neither path raises the overflow flag (with the fixed-size
+    samples of the 1 M design every call at this size fell back to the all-fp32 kernels).  Results still
+    equal the all-fp32 scan / the fp32 lists bit for bit."""
+    from aura_snn_rag_amd import ops
+    from aura_snn_rag_amd.core.hippocampal import HippocampalFormation
+    N, D, k = 6_000_000, 64, 32
+    hf = HippocampalFormation(feature_dim=D, max_memories=N, n_place_cells=8, n_time_cells=4, n_grid_cells=4,
+                              device="cuda", use_centroid_index=True)
+    g = torch.Generator(device=dev).manual_seed(99)
+    for r0 in range(0, N, 1 << 20):
+        n = min(1 << 20, N - r0)
+        hf.bulk_write(torch.randn(n, D, generator=g, device=dev), rebuild=False)
+    hf.rebuild_centroids()
+    now = float(hf.memory_metadata[0, 1].item()) + 5.0
+    pick = torch.randint(0, N, (200,), generator=g, device=dev)
+    q = torch.cat([hf.memory_features[pick] + 0.05 * torch.randn(200, D, generator=g, device=dev),
+                   torch.randn(100, D, generator=g, device=dev)]).contiguous()
+    # full scan through the bf16 shadow
+    shadow = hf._ensure_shadow()
+    assert shadow is not None
+    s2, r2, flag = ops.knn_search(hf.memory_features, hf._inv_norm, hf.memory_metadata, q, k, now, count=N,
+                                  shadow=shadow, rho=hf._rho, check_overflow=False, return_flag=True)
+    assert int(flag) == 0, f"full scan raised flag {int(flag)} at {N} rows"
+    s0, r0 = ops.knn_search(hf.memory_features, hf._inv_norm, hf.memory_metadata, q, k, now, count=N, fp32_scan=True)
+    assert torch.equal(r0, r2) and torch.equal(s0, s2)
+    assert bool((r2[:200, 0] == pick.to(torch.int32)).all())
+    # centroid index through the inverted lists on the two-stage scan
+    s_c, r_c = hf.recall_batch(q, k=k, now=now, check_overflow=False, fallback_empty=False)
+    ivf = hf._ivf
+    assert ivf is not None and ivf.valid
+    flag_c = int(ops._overflow_flag(q.device).item())
+    assert flag_c & ~ops.KNN_FLAG_NO_CANDIDATES == 0, f"inverted lists raised flag {flag_c} at {N} rows"
+    s_m, r_m = ops.knn_search(hf.memory_features, hf._inv_norm, hf.memory_metadata, q, k, now, count=N,
+                              centroids=hf.centroids, nprobe=8, fp32_scan=True)
+    assert torch.equal(r_m, r_c) and torch.equal(s_m, s_c)
+    del hf
+    torch.cuda.empty_cache()
