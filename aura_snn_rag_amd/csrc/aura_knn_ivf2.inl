@@ -148,6 +148,15 @@ __global__ __launch_bounds__(256) void ivf2_prep_kernel(const float* __restrict_
         thr[vs] = 0xff800000u;                             // ord_key(+inf): nothing passes until the
         if (used) qslot[(int64_t)q * 8 + p] = (int32_t)vs; // threshold kernel lowers it
     }
+    // Slots are filled in order, and the scan multiplies a wave's column blocks only if the wave holds a
+    // query (coarse_scan_kernel; a wave is 32 or 64 slots): a 64-slot group without any query is never
+    // read, so its 96 KB of fragments are not written -- about half of this kernel's writes at 8 probes x
+    // 2048 queries over 256 lists.  Unused slots INSIDE a group that is read get zeros, as before: an
+    // accumulator of a padding column must stay finite (+inf would pass its +inf threshold).
+    if ((ls & ~63) >= lq_cnt[list]) {
+        if (lane == 0) eq_slot[vs] = 0.0f;
+        return;
+    }
     const int wq = (int)(vs >> 6) & 3, b = (int)(vs >> 4) & 3, lr = (int)vs & 15;
     uint16_t* const base = qhat + (((((int64_t)B * 4 + wq) * 4 + b) * KS) * 64 + lr) * 8;
     float s = 0.0f;
