@@ -563,6 +563,7 @@ class HippocampalFormation(nn.Module):
                                   shadow=shadow, rho=self._rho if shadow is not None else None, **kw)
         nprobe = min(8, self.centroids_k)
         scores = rows = ovf = None
+        self._last_flag = None
         full_index = self.centroids.shape[0] == 256
         masked_ok = (q_loc is None and full_index and self.memory_count <= self.MASKED_SCAN_MAX_ROWS and
                      q.shape[0] <= self.MASKED_SCAN_MAX_QUERIES)
@@ -598,6 +599,7 @@ class HippocampalFormation(nn.Module):
             if f & ~ops.KNN_FLAG_NO_CANDIDATES:
                 scores = rows = None                  # candidate lists too long: the fp32 paths below
             elif not (f & ops.KNN_FLAG_NO_CANDIDATES) or not fallback_empty:
+                self._last_flag = f                   # (sharded.ShardedHippocampus: was any query left without candidates?)
                 return scores, rows
         if scores is None and q_loc is None and full_index:
             # fp32 inverted lists: every probed list is streamed once per batch

@@ -22,14 +22,15 @@
 
 constexpr int IVF2_STILES = 32;            // sample tiles (of 16 rows) per list, at least
 constexpr int IVF2_STILES_MAX = 256;       // ... and at most
-// Sample tiles per list for a sorted shadow of n_sorted rows: about an eighth of an average list (so that
-// the k-th best of the sample sits near rank 8 k of the probed rows whatever the bank's size -- with a
-// fixed 32 tiles a 10 M-row bank's queries collected more candidates than the refine stage holds and
-// every call fell back to the fp32 lists), a power of two in [32, 256].
+// Sample tiles per list for a sorted shadow of n_sorted rows (slack included): at least a twelfth of an
+// average list, so that the k-th best of the sample sits near rank 8..12 k of the probed rows whatever the
+// bank's size -- with a fixed 32 tiles a 10 M-row bank's queries collected more candidates than the refine
+// stage holds and every call fell back to the fp32 lists -- a power of two in [32, 256].  (At 1 M rows 64
+// tiles instead of 32 cost 35 us more in the sample scan and threshold launches and saved 15 in the refine.)
 static inline int ivf2_stiles(int64_t n_sorted) {
     const int64_t avg_tiles = n_sorted / 16 / 256;
     int st = IVF2_STILES;
-    while (st < IVF2_STILES_MAX && (int64_t)st * 8 < avg_tiles) st *= 2;
+    while (st < IVF2_STILES_MAX && (int64_t)st * 12 < avg_tiles) st *= 2;
     return st;
 }
 constexpr int IVF2_MAXBLK = 256 + IVF_MAXQ * 8 / 256;   // blocks of one pass at most

@@ -268,7 +268,8 @@ class ShardedHippocampus:
         if loc.memory_count == 0:
             s = torch.full((q.shape[0], kk), float("-inf"), device=q.device)
             return s, torch.full((q.shape[0], kk), -1, dtype=torch.int32, device=q.device)
-        s, r = loc.recall_batch(q, k=kk, fallback_empty=False, **self._recall_kw)
+        # one rank: the bank's own empty-candidate fallback (no second host read for the merged result)
+        s, r = loc.recall_batch(q, k=kk, fallback_empty=self.world == 1, **self._recall_kw)
         if s.shape[1] < kk:                        # a shard with fewer than k rows: pad
             pad = kk - s.shape[1]
             s = torch.cat([s, torch.full((s.shape[0], pad), float("-inf"), device=s.device)], dim=1)
@@ -297,7 +298,12 @@ class ShardedHippocampus:
             allq = q
         s, r = self._recall.recall(allq, int(k))
         cand = self.local._candidate_mode() if use_candidates is None else (use_candidates and self.local._candidate_mode())
-        if cand and check_overflow and bool((r[:, 0] < 0).any()):
+        # A query is without candidates on EVERY rank only if this rank's flag says so for some query: the
+        # host read of the merged result is skipped otherwise (the decision is the same on all ranks whenever
+        # such a query exists, so the fallback's collectives stay matched).
+        lf = getattr(self.local, "_last_flag", None)
+        may_be_empty = self.world > 1 and (lf is None or bool(lf & getattr(self.ops, "KNN_FLAG_NO_CANDIDATES", 64)))
+        if cand and check_overflow and may_be_empty and bool((r[:, 0] < 0).any()):
             # no shard had a candidate for these queries: the reference falls back to the full scan (:269-270)
             sel = torch.nonzero(r[:, 0] < 0).flatten()
             self._recall_kw["use_candidates"] = False
