@@ -912,9 +912,15 @@ __global__ __launch_bounds__(256) void centroid_dist_kernel(const float* __restr
     if (q0 + qs + 1 < nq) dist[(int64_t)(q0 + qs + 1) * 256 + c0 + cl] = sqrtf(acc1);
 }
 
+// lq_cnt / lq_list (optional): the per-list query lists of the inverted-list recall, filled here (one
+// returning atomic per probe on the list's counter, zeroed by the caller) instead of by a one-workgroup
+// pass over all (query, probe) pairs afterwards; the order inside a list is whatever the atomics make it
+// (results do not depend on it).
 __global__ __launch_bounds__(256) void probe_select_kernel(const float* __restrict__ dist, int nprobe,
                                                            uint32_t* __restrict__ mask_out,
-                                                           int32_t* __restrict__ ids_out) {
+                                                           int32_t* __restrict__ ids_out,
+                                                           int32_t* __restrict__ lq_cnt,
+                                                           int32_t* __restrict__ lq_list, int lq_stride) {
     __shared__ float s_bv[4];
     __shared__ int s_bi[4];
     __shared__ uint32_t s_m[8];
@@ -941,6 +947,10 @@ __global__ __launch_bounds__(256) void probe_select_kernel(const float* __restri
             mine = INFINITY;
             s_m[bi >> 5] |= 1u << (bi & 31);
             if (ids_out && p < 8) ids_out[(int64_t)blockIdx.x * 8 + p] = bi;
+            if (lq_cnt && p < 8) {
+                const int slot = atomicAdd(&lq_cnt[bi], 1);
+                if (slot < lq_stride) lq_list[(int64_t)bi * lq_stride + slot] = ((int)blockIdx.x << 4) | p;
+            }
         }
         __syncthreads();
     }
@@ -949,12 +959,13 @@ __global__ __launch_bounds__(256) void probe_select_kernel(const float* __restri
 
 // probe = distances + selection; dist_ws: nq*256 floats of scratch
 inline int launch_probe(const float* centroids, const float* queries, int64_t D, int nq, int nprobe,
-                        float* dist_ws, uint32_t* mask_out, int32_t* ids_out, hipStream_t s) {
+                        float* dist_ws, uint32_t* mask_out, int32_t* ids_out, hipStream_t s,
+                        int32_t* lq_cnt = nullptr, int32_t* lq_list = nullptr, int lq_stride = 0) {
     hipLaunchKernelGGL(centroid_dist_kernel, dim3(256 / PD_C, (unsigned)((nq + PD_Q - 1) / PD_Q)),
                        dim3(256), 0, s, centroids, queries, D, nq, dist_ws);
     if (hipGetLastError() != hipSuccess) return AURA_E_LAUNCH;
     hipLaunchKernelGGL(probe_select_kernel, dim3((unsigned)nq), dim3(256), 0, s, dist_ws, nprobe,
-                       mask_out, ids_out);
+                       mask_out, ids_out, lq_cnt, lq_list, lq_stride);
     return hipGetLastError() == hipSuccess ? AURA_OK : AURA_E_LAUNCH;
 }
 
@@ -2151,14 +2162,11 @@ int aura_knn_search_ivf2(const float* bank, const float* inv_norm, const float* 
     for (int64_t qb0 = 0; qb0 < nq; qb0 += w.qp) {
         const int nqb = (int)((nq - qb0) < w.qp ? (nq - qb0) : w.qp);
         const float* qptr = queries + qb0 * D;
-        if ((rc = launch_probe(centroids, qptr, D, nqb, nprobe, w.probe_dist, w.probe, w.probe_ids, s))) return rc;
+        // the probe launch also fills the per-list query lists (lq_cnt / lq_list)
+        if (hipMemsetAsync(w.lq_cnt, 0, 256 * 4, s) != hipSuccess) return AURA_E_LAUNCH;
+        if ((rc = launch_probe(centroids, qptr, D, nqb, nprobe, w.probe_dist, w.probe, w.probe_ids, s,
+                               w.lq_cnt, w.lq_list, IVF_MAXQ))) return rc;
         stage("probe");
-        // per-list query lists (the fp32 lists path's preparation; its capacity bookkeeping is unused)
-        hipLaunchKernelGGL(ivf_prepare_kernel, dim3(1), dim3(256), 0, s, w.probe_ids, nprobe, nqb,
-                           list_len, w.lq_cnt, w.lq_list, w.qbase, w.cnt, w.item_off_old,
-                           w.work_counter, 0x7fffffff, 32, nullptr);
-        if ((rc = check_launch())) return rc;
-        stage("prepare");
         hipLaunchKernelGGL(ivf2_plan_kernel, dim3(1), dim3(256), 0, s, w.lq_cnt, pad_off, list_len, w.blk_off,
                            w.blk_list, w.blk_row0, w.blk_stride, w.blk_nq, w.item_off, w.sitem_off, w.nblk,
                            stiles, w_sparse, w_dense);
