@@ -2174,14 +2174,14 @@ int aura_knn_search_ivf2(const float* bank, const float* inv_norm, const float* 
         // the probe launch also fills the per-list query lists (lq_cnt / lq_list)
         if (hipMemsetAsync(w.lq_cnt, 0, 256 * 4, s) != hipSuccess) return AURA_E_LAUNCH;
         if ((rc = launch_probe(centroids, qptr, D, nqb, nprobe, w.probe_dist, w.probe, w.probe_ids, s,
-                               w.lq_cnt, w.lq_list, IVF_MAXQ))) return rc;
+                               w.lq_cnt, w.lq_list, IVF2_MAXQ))) return rc;
         stage("probe");
         hipLaunchKernelGGL(ivf2_plan_kernel, dim3(1), dim3(256), 0, s, w.lq_cnt, pad_off, list_len, w.blk_off,
                            w.blk_list, w.blk_row0, w.blk_stride, w.blk_nq, w.item_off, w.sitem_off, w.nblk,
                            stiles, w_sparse, w_dense);
         if ((rc = check_launch())) return rc;
         stage("plan");
-        const int qblocks = IVF2_MAXBLK * 256 / 4;            // query slots only (the rows' part ran above)
+        const int qblocks = ivf2_maxblk(w.qp) * 256 / 4;      // query slots only (the rows' part ran above)
         hipLaunchKernelGGL(ivf2_prep_kernel, dim3((unsigned)qblocks), dim3(256), 0, s,
                            qptr, (int64_t)nqb, D, KS, w.lq_cnt, w.lq_list, w.blk_off, w.blk_list, w.nblk, w.qhat,
                            w.inv_q, w.slotq, w.qslot, w.thr, qb0 == 0 ? overflow_out : nullptr, lists_flag, w.eq_slot, w.eq_q,
@@ -2192,7 +2192,7 @@ int aura_knn_search_ivf2(const float* bank, const float* inv_norm, const float* 
         CoarseArgs c{};
         c.bank = bank; c.bank16 = sorted_bf16; c.rowc = w.rowc; c.qhat = w.qhat; c.inv_q = w.inv_q;
         c.eq = w.eq_slot;
-        c.N = n_sorted; c.D = D; c.nq = IVF2_MAXBLK * 256;
+        c.N = n_sorted; c.D = D; c.nq = ivf2_maxblk(w.qp) * 256;
         c.thr = w.thr; c.cnt = w.cnt; c.cand_scores = w.cand_scores; c.cand_idx = w.cand_idx; c.cap = w.cap;
         c.blk_row0 = w.blk_row0; c.blk_stride = w.blk_stride; c.nblk = w.nblk; c.slotq = w.slotq;
         c.blk_nq = w.blk_nq; c.w_sparse = w_sparse; c.w_dense = w_dense;

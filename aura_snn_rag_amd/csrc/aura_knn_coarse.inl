@@ -54,7 +54,7 @@ constexpr int CS_THREADS = 256;           // 4 waves (one per SIMD, 512 register
 constexpr int CS_QB = 4;                 // 16-query MFMA column blocks per wave
 constexpr int CS_ROWS = 16;              // bank rows per tile
 constexpr int CS_SLOTS = 3;
-constexpr int IVF2_MAXBLK_C = 320;       // = IVF2_MAXBLK (aura_knn_ivf2.inl; checked there): blocks of one inverted-list pass at most
+constexpr int IVF2_MAXBLK_C = 512;       // = IVF2_MAXBLK (aura_knn_ivf2.inl; checked there): blocks of one inverted-list pass at most
 // bf16-row 8-wave kernels (not the probe-mask form, whose masks need the LDS) allocate twice the ring:
 // their row-split form (blocks of at most 128 queries) streams two 16-row tiles per step
 template <bool SRC16, bool MASKED, int NW> constexpr int cs_lds_slots() { return (SRC16 && NW == 8 && !MASKED) ? 2 * CS_SLOTS : CS_SLOTS; }

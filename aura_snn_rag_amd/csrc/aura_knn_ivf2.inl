@@ -33,7 +33,13 @@ static inline int ivf2_stiles(int64_t n_sorted) {
     while (st < IVF2_STILES_MAX && (int64_t)st * 12 < avg_tiles) st *= 2;
     return st;
 }
-constexpr int IVF2_MAXBLK = 256 + IVF_MAXQ * 8 / 256;   // blocks of one pass at most
+constexpr int IVF2_MAXQ = 8192;            // queries per pass: every probed list is streamed once per 256 of the
+                                           // queries that probe it, so large batches (bulk recall, the all-gathered
+                                           // query blocks of a sharded bank) want long passes; workspace grows with
+                                           // min(nq, IVF2_MAXQ) (2048 queries: as in r01)
+// blocks of a pass of qp queries at most: sum over the lists of ceil(count / 256) <= 256 + 8 qp / 256
+static inline int ivf2_maxblk(int64_t qp) { return 256 + (int)((qp * 8 + 255) / 256); }
+constexpr int IVF2_MAXBLK = 256 + IVF2_MAXQ * 8 / 256;
 static_assert(IVF2_MAXBLK == IVF2_MAXBLK_C, "coarse_scan_kernel's block search covers IVF2_MAXBLK_C prefixes");
 
 // ---- plan: blocks, their row ranges and the work-item prefixes (one workgroup) ----
@@ -103,7 +109,7 @@ __global__ __launch_bounds__(256) void ivf2_plan_kernel(const int32_t* __restric
 //      per sorted row the score constants (with the bank row id's bits in .w) ----
 __global__ __launch_bounds__(256) void ivf2_prep_kernel(const float* __restrict__ x, int64_t nq, int64_t D, int KS,
                                                         const int32_t* __restrict__ lq_cnt,
-                                                        const int32_t* __restrict__ lq_list,
+                                                        const int32_t* __restrict__ lq_list,   // [256][IVF2_MAXQ]
                                                         const int32_t* __restrict__ blk_off,
                                                         const int32_t* __restrict__ blk_list,
                                                         const int32_t* __restrict__ nblk,
@@ -141,7 +147,7 @@ __global__ __launch_bounds__(256) void ivf2_prep_kernel(const float* __restrict_
     const bool used = ls < lq_cnt[list];
     int q = -1, p = 0;
     if (used) {
-        const int packed = lq_list[(int64_t)list * IVF_MAXQ + ls];
+        const int packed = lq_list[(int64_t)list * IVF2_MAXQ + ls];
         q = packed >> 4; p = packed & 15;
     }
     if (lane == 0) {
@@ -267,15 +273,16 @@ static Ivf2Workspace carve_ivf2(void* base, int64_t Npad, int64_t nq, int k) {
         off += align_up(bytes, 256);
         return r;
     };
-    int64_t qp = nq < IVF_MAXQ ? (nq > 0 ? nq : 1) : IVF_MAXQ;
+    int64_t qp = nq < IVF2_MAXQ ? (nq > 0 ? nq : 1) : IVF2_MAXQ;
     w.qp = (int)qp;
+    const int64_t mb = ivf2_maxblk(qp);                    // blocks, and mb * 256 query slots
     w.cap = RF_CAP;                                         // refine holds at most this many per query
     w.inv_q = reinterpret_cast<float*>(take(qp * 4));
     w.probe = reinterpret_cast<uint32_t*>(take(qp * 32));
     w.probe_dist = reinterpret_cast<float*>(take(qp * 256 * 4));
     w.probe_ids = reinterpret_cast<int32_t*>(take(qp * 8 * 4));
     w.lq_cnt = reinterpret_cast<int32_t*>(take(256 * 4));
-    w.lq_list = reinterpret_cast<int32_t*>(take((int64_t)256 * IVF_MAXQ * 4));
+    w.lq_list = reinterpret_cast<int32_t*>(take((int64_t)256 * IVF2_MAXQ * 4));
     w.qbase = reinterpret_cast<int32_t*>(take(qp * 8 * 4));
     w.item_off_old = reinterpret_cast<int32_t*>(take(257 * 4));
     w.work_counter = reinterpret_cast<int32_t*>(take(256));
@@ -283,20 +290,20 @@ static Ivf2Workspace carve_ivf2(void* base, int64_t Npad, int64_t nq, int k) {
     w.cand_scores = reinterpret_cast<float*>(take(qp * w.cap * 4));
     w.cand_idx = reinterpret_cast<int32_t*>(take(qp * w.cap * 4));
     w.blk_off = reinterpret_cast<int32_t*>(take(257 * 4));
-    w.blk_list = reinterpret_cast<int32_t*>(take(IVF2_MAXBLK * 4));
-    w.blk_row0 = reinterpret_cast<int32_t*>(take(IVF2_MAXBLK * 4));
-    w.blk_stride = reinterpret_cast<int32_t*>(take(IVF2_MAXBLK * 4));
-    w.blk_nq = reinterpret_cast<int32_t*>(take(IVF2_MAXBLK * 4));
-    w.item_off = reinterpret_cast<int32_t*>(take((IVF2_MAXBLK + 1) * 4));
-    w.sitem_off = reinterpret_cast<int32_t*>(take((IVF2_MAXBLK + 1) * 4));
+    w.blk_list = reinterpret_cast<int32_t*>(take(mb * 4));
+    w.blk_row0 = reinterpret_cast<int32_t*>(take(mb * 4));
+    w.blk_stride = reinterpret_cast<int32_t*>(take(mb * 4));
+    w.blk_nq = reinterpret_cast<int32_t*>(take(mb * 4));
+    w.item_off = reinterpret_cast<int32_t*>(take((mb + 1) * 4));
+    w.sitem_off = reinterpret_cast<int32_t*>(take((mb + 1) * 4));
     w.nblk = reinterpret_cast<int32_t*>(take(256));
-    w.slotq = reinterpret_cast<int32_t*>(take((int64_t)IVF2_MAXBLK * 256 * 4));
+    w.slotq = reinterpret_cast<int32_t*>(take(mb * 256 * 4));
     w.qslot = reinterpret_cast<int32_t*>(take(qp * 8 * 4));
-    w.thr = reinterpret_cast<uint32_t*>(take((int64_t)IVF2_MAXBLK * 256 * 4));
-    w.eq_slot = reinterpret_cast<float*>(take((int64_t)IVF2_MAXBLK * 256 * 4));
+    w.thr = reinterpret_cast<uint32_t*>(take(mb * 256 * 4));
+    w.eq_slot = reinterpret_cast<float*>(take(mb * 256 * 4));
     w.eq_q = reinterpret_cast<float*>(take(qp * 4));
-    w.gmax = reinterpret_cast<float*>(take((int64_t)IVF2_MAXBLK * 256 * 2 * ivf2_stiles(Npad) * 4));
-    w.qhat = reinterpret_cast<uint16_t*>(take((int64_t)IVF2_MAXBLK * 256 * 768 * 2));
+    w.gmax = reinterpret_cast<float*>(take(mb * 256 * 2 * ivf2_stiles(Npad) * 4));
+    w.qhat = reinterpret_cast<uint16_t*>(take(mb * 256 * 768 * 2));
     w.rowc = reinterpret_cast<float4*>(take((Npad > 0 ? Npad : 1) * 16));
     w.bytes = off;
     return w;

@@ -13,7 +13,7 @@ def sweep(cases=30, seed=0, dev=None, verbose=True):
     ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g).item())
     bad = 0
     for c in range(cases):
-        N = ri(8192, 120000); D = 8 * ri(1, 96); nq = [1, 9, 100, 256, 700, 2500][ri(0, 5)]
+        N = ri(8192, 120000); D = 8 * ri(1, 96); nq = [1, 9, 100, 256, 700, 2500, 8300][ri(0, 6)]
         k = [1, 5, 32, 64, 150][ri(0, 4)]; ncent = [256, 256, 200, 60][ri(0, 3)]
         x = torch.randn(N, D, generator=g)
         if ri(0, 1):

@@ -516,10 +516,10 @@ def _lists_of(meta_dev, N):
 
 @pytest.mark.parametrize("N,D,nq,k,ncent", [(20000, 64, 100, 10, 200), (100000, 768, 256, 32, 256),
                                             (33333, 200, 1, 5, 256), (50000, 512, 2300, 64, 40),
-                                            (16000, 8, 700, 200, 256)])
+                                            (16000, 8, 700, 200, 256), (30000, 32, 9000, 16, 256)])
 def test_inverted_lists_two_stage(dev, N, D, nq, k, ncent):
     """Inverted lists on the two-stage scan == the fp32 lists == the masked scan, bit for bit: few
-    centroids (lists probed by > 256 queries -> several blocks per list, > 2048 queries -> several
+    centroids (lists probed by > 256 queries -> several blocks per list, > 8192 queries -> several
     passes), empty lists, rows without a centroid, a query that probes only empty centroids."""
     from aura_snn_rag_amd import ops
     g = torch.Generator().manual_seed(N + D + nq)
