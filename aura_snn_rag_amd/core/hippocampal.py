@@ -528,7 +528,8 @@ class HippocampalFormation(nn.Module):
     def recall_batch(self, queries: torch.Tensor, k: int = 5,
                      locations: Optional[torch.Tensor] = None, now: Optional[float] = None,
                      use_candidates: Optional[bool] = None, check_overflow: bool = True,
-                     fallback_empty: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+                     fallback_empty: bool = True,
+                     probe_ids: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         """Batched recall: ``(scores [nq, k'], rows [nq, k'])`` with ``k' = min(k, count)``;
         rows are bank row indices (int32), ``-1`` where a query has fewer than ``k'`` candidates.
 
@@ -538,7 +539,9 @@ class HippocampalFormation(nn.Module):
         (it then falls back to the full scan, reference ``:269-270``).  Pass False only inside
         latency-critical loops whose data is known to be well behaved.  ``fallback_empty=False``
         leaves such queries at ``-1`` (a shard of a row-sharded bank: the query may have candidates
-        on another shard, so the fallback is the caller's decision after the merge)."""
+        on another shard, so the fallback is the caller's decision after the merge).  ``probe_ids``:
+        ``probe(queries)`` computed earlier for these queries against the current centroid table (the
+        inverted-list path then skips its own probe; other paths ignore it)."""
         if self.memory_count == 0:
             z = torch.empty(queries.shape[0], 0, device=self.device)
             return z, z.to(torch.int32)
@@ -587,7 +590,8 @@ class HippocampalFormation(nn.Module):
                 scores, rows, ovf = ops.knn_search_ivf2(self.memory_features, self._inv_norm, self.memory_metadata,
                                                         q, kk, now, self.centroids, nprobe, ivf.sorted_bf16,
                                                         self._rho, ivf.sorted_rows, ivf.pad_off, ivf.list_len,
-                                                        n_sorted=ivf.n_sorted, lists_flag=ivf.flag)
+                                                        n_sorted=ivf.n_sorted, lists_flag=ivf.flag,
+                                                        probe_ids=probe_ids)
         if check_overflow and scores is not None:
             # ONE host read for both conditions: the library's flag carries the overflow bits of the
             # two-stage lists and the "a query has no candidate at all" bit
@@ -595,7 +599,8 @@ class HippocampalFormation(nn.Module):
             if f & ops.KNN_FLAG_LISTS_STALE:          # a write outgrew a list's slack: re-pack, then once more
                 self._ivf.valid = False
                 return self.recall_batch(queries, k=k, locations=locations, now=now, use_candidates=use_candidates,
-                                         check_overflow=check_overflow, fallback_empty=fallback_empty)
+                                         check_overflow=check_overflow, fallback_empty=fallback_empty,
+                                         probe_ids=probe_ids)
             if f & ~ops.KNN_FLAG_NO_CANDIDATES:
                 scores = rows = None                  # candidate lists too long: the fp32 paths below
             elif not (f & ops.KNN_FLAG_NO_CANDIDATES) or not fallback_empty:
@@ -626,6 +631,15 @@ class HippocampalFormation(nn.Module):
                                     q[sel].contiguous(), kk, now, **kw2)
             scores[sel], rows[sel] = s2, r2
         return scores, rows
+
+    def probe(self, queries: torch.Tensor) -> Optional[torch.Tensor]:
+        """The centroid probes of ``queries`` ([nq, 8] int32, the 8 nearest of the 256 centroid rows in
+        distance order, reference ``:261-262``) for ``recall_batch(..., probe_ids=...)``, or None when the
+        index is not in use.  Ranks of a sharded bank share one centroid table, so a query is probed once,
+        by the rank that brings it."""
+        if not self._candidate_mode() or self.centroids.shape[0] != 256 or not self.memory_features.is_cuda:
+            return None
+        return ops.centroid_probe(self._features_to_device(queries), self.centroids, min(8, self.centroids_k))
 
     def retrieve_similar_memories(self, query_features: torch.Tensor,
                                   location: Optional[torch.Tensor] = None,

@@ -2105,19 +2105,36 @@ int aura_knn_search_shadow(const float* bank, const uint16_t* bank_bf16, const f
                            centroids, nprobe, stream);
 }
 
+int64_t aura_centroid_probe_workspace_bytes(int64_t nq) {
+    if (nq < 0) return -1;
+    return align_up(nq * 256 * 4, 256) + align_up(nq * 32, 256) + 256;
+}
+
 int64_t aura_knn_ivf2_workspace_bytes(int64_t n_sorted, int64_t nq, int k) {
     if (n_sorted < 0 || nq < 0 || k <= 0) return -1;
     return carve_ivf2(nullptr, n_sorted, nq, k).bytes;
 }
 
-int aura_knn_search_ivf2(const float* bank, const float* inv_norm, const float* meta,
+int aura_centroid_probe(const float* centroids, const float* queries, int64_t D, int64_t nq, int nprobe,
+                        int32_t* ids_out, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (D <= 0 || nq < 0 || nq > 0x7fffffffLL / 256 || nprobe <= 0 || nprobe > 8) return AURA_E_INVAL;
+    if (nq == 0) return AURA_OK;
+    if (!centroids || !queries || !ids_out || !workspace) return AURA_E_INVAL;
+    if (reinterpret_cast<uintptr_t>(workspace) & 255) return AURA_E_ALIGN;
+    if (workspace_bytes < aura_centroid_probe_workspace_bytes(nq)) return AURA_E_INVAL;
+    float* const dist = static_cast<float*>(workspace);
+    uint32_t* const mask = reinterpret_cast<uint32_t*>(static_cast<char*>(workspace) + align_up(nq * 256 * 4, 256));
+    return launch_probe(centroids, queries, D, (int)nq, nprobe, dist, mask, ids_out, static_cast<hipStream_t>(stream));
+}
+
+static int knn_search_ivf2_impl(const float* bank, const float* inv_norm, const float* meta,
                          const uint16_t* sorted_bf16, const float* rho, const int32_t* sorted_rows, const int32_t* pad_off,
                          const int32_t* list_len, const int32_t* lists_flag, int64_t n_sorted, int64_t N,
                          const float* queries, float now,
                          int64_t D, int64_t nq, int k,
                          const float* centroids, int nprobe, int32_t idx_base, float* out_scores,
                          int32_t* out_idx, void* workspace, int64_t workspace_bytes,
-                         int32_t* overflow_out, void* stream) {
+                         int32_t* overflow_out, const int32_t* probe_ids, void* stream) {
     if (n_sorted <= 0 || N <= 0 || N > 0x7ffffff0LL || D <= 0 || D > 768 || (D & 7) || nq < 0 || k <= 0 ||
         k > COARSE_MAX_K)
         return AURA_E_INVAL;
@@ -2171,10 +2188,15 @@ int aura_knn_search_ivf2(const float* bank, const float* inv_norm, const float* 
     for (int64_t qb0 = 0; qb0 < nq; qb0 += w.qp) {
         const int nqb = (int)((nq - qb0) < w.qp ? (nq - qb0) : w.qp);
         const float* qptr = queries + qb0 * D;
-        // the probe launch also fills the per-list query lists (lq_cnt / lq_list)
+        // the probe launch also fills the per-list query lists (lq_cnt / lq_list); probes that the caller
+        // already has (a sharded bank computes them once per query, not once per rank) only fill the lists
         if (hipMemsetAsync(w.lq_cnt, 0, 256 * 4, s) != hipSuccess) return AURA_E_LAUNCH;
-        if ((rc = launch_probe(centroids, qptr, D, nqb, nprobe, w.probe_dist, w.probe, w.probe_ids, s,
-                               w.lq_cnt, w.lq_list, IVF2_MAXQ))) return rc;
+        if (probe_ids) {
+            hipLaunchKernelGGL(ivf2_lists_from_ids_kernel, dim3((unsigned)((nqb * 8 + 255) / 256)), dim3(256), 0, s,
+                               probe_ids + qb0 * 8, nqb, nprobe, w.lq_cnt, w.lq_list);
+            if ((rc = check_launch())) return rc;
+        } else if ((rc = launch_probe(centroids, qptr, D, nqb, nprobe, w.probe_dist, w.probe, w.probe_ids, s,
+                                      w.lq_cnt, w.lq_list, IVF2_MAXQ))) return rc;
         stage("probe");
         hipLaunchKernelGGL(ivf2_plan_kernel, dim3(1), dim3(256), 0, s, w.lq_cnt, pad_off, list_len, w.blk_off,
                            w.blk_list, w.blk_row0, w.blk_stride, w.blk_nq, w.item_off, w.sitem_off, w.nblk,
@@ -2289,6 +2311,31 @@ int aura_knn_search_ivf2(const float* bank, const float* inv_norm, const float* 
         stage("refine");
     }
     return AURA_OK;
+}
+
+int aura_knn_search_ivf2(const float* bank, const float* inv_norm, const float* meta,
+                         const uint16_t* sorted_bf16, const float* rho, const int32_t* sorted_rows, const int32_t* pad_off,
+                         const int32_t* list_len, const int32_t* lists_flag, int64_t n_sorted, int64_t N,
+                         const float* queries, float now, int64_t D, int64_t nq, int k,
+                         const float* centroids, int nprobe, int32_t idx_base, float* out_scores,
+                         int32_t* out_idx, void* workspace, int64_t workspace_bytes,
+                         int32_t* overflow_out, void* stream) {
+    return knn_search_ivf2_impl(bank, inv_norm, meta, sorted_bf16, rho, sorted_rows, pad_off, list_len, lists_flag,
+                                n_sorted, N, queries, now, D, nq, k, centroids, nprobe, idx_base, out_scores, out_idx,
+                                workspace, workspace_bytes, overflow_out, nullptr, stream);
+}
+
+int aura_knn_search_ivf2_probed(const float* bank, const float* inv_norm, const float* meta,
+                                const uint16_t* sorted_bf16, const float* rho, const int32_t* sorted_rows,
+                                const int32_t* pad_off, const int32_t* list_len, const int32_t* lists_flag,
+                                int64_t n_sorted, int64_t N, const float* queries, float now, int64_t D, int64_t nq,
+                                int k, const float* centroids, int nprobe, const int32_t* probe_ids, int32_t idx_base,
+                                float* out_scores, int32_t* out_idx, void* workspace, int64_t workspace_bytes,
+                                int32_t* overflow_out, void* stream) {
+    if (!probe_ids) return AURA_E_INVAL;
+    return knn_search_ivf2_impl(bank, inv_norm, meta, sorted_bf16, rho, sorted_rows, pad_off, list_len, lists_flag,
+                                n_sorted, N, queries, now, D, nq, k, centroids, nprobe, idx_base, out_scores, out_idx,
+                                workspace, workspace_bytes, overflow_out, probe_ids, stream);
 }
 
 int aura_knn_search(const float* bank, const float* inv_norm, const float* meta, const float* loc,

@@ -105,6 +105,19 @@ __global__ __launch_bounds__(256) void ivf2_plan_kernel(const int32_t* __restric
     if (tid == 0) { item_off[s_nb[256]] = s_it[256]; sitem_off[s_nb[256]] = s_st[256]; }
 }
 
+// ---- per-list query lists from probe ids the caller already has (aura_knn_search_ivf2_probed) ----
+__global__ __launch_bounds__(256) void ivf2_lists_from_ids_kernel(const int32_t* __restrict__ ids,   // [nq][8]
+                                                                  int nq, int nprobe, int32_t* lq_cnt,
+                                                                  int32_t* __restrict__ lq_list) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int q = t >> 3, p = t & 7;
+    if (q >= nq || p >= nprobe) return;
+    const int c = ids[t];
+    if ((unsigned)c >= 256u) return;                       // not a centroid row: the probe is dropped
+    const int slot = atomicAdd(&lq_cnt[c], 1);
+    if (slot < IVF2_MAXQ) lq_list[(int64_t)c * IVF2_MAXQ + slot] = (q << 4) | p;
+}
+
 // ---- prep: per block slot the query's bf16 fragments, the slot <-> query maps, +inf thresholds;
 //      per sorted row the score constants (with the bank row id's bits in .w) ----
 __global__ __launch_bounds__(256) void ivf2_prep_kernel(const float* __restrict__ x, int64_t nq, int64_t D, int KS,

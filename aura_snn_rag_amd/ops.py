@@ -537,15 +537,36 @@ def ivf2_append(bank, inv_norm, meta, slots, sorted_shadow, sorted_rows, pad_off
                                  _stream()), "aura_ivf2_append")
 
 
+def centroid_probe(queries, centroids, nprobe: int = 8) -> torch.Tensor:
+    """ids [nq, 8] int32: column p < nprobe = the p-th nearest of the 256 centroid rows to each query (L2 on the
+    unnormalised query, ties to the lower row, ``hippocampal.py:261-262``) -- the probes ``knn_search_ivf2``
+    computes for itself, for callers that want them once per query (``sharded.ShardedHippocampus``)."""
+    _need(queries, "queries", torch.float32); _need(centroids, "centroids", torch.float32)
+    nq, D = queries.shape
+    if centroids.shape != (256, D) or not (0 < nprobe <= 8):
+        raise ValueError("centroid_probe: centroids must be [256, D], nprobe in [1, 8]")
+    ids = torch.full((nq, 8), -1, dtype=torch.int32, device=queries.device)
+    if nq == 0:
+        return ids
+    L = lib()
+    nbytes = L.aura_centroid_probe_workspace_bytes(nq)
+    ws = _workspace(queries.device, nbytes)
+    base = (ws.data_ptr() + 255) // 256 * 256
+    check(L.aura_centroid_probe(_p(centroids), _p(queries), D, nq, nprobe, _p(ids), base, nbytes, _stream()),
+          "aura_centroid_probe")
+    return ids
+
+
 def knn_search_ivf2(bank, inv_norm, meta, queries, k: int, now: float, centroids, nprobe: int,
                     sorted_shadow, rho, sorted_rows, pad_off, list_len, idx_base: int = 0,
-                    n_sorted: Optional[int] = None, lists_flag=None
+                    n_sorted: Optional[int] = None, lists_flag=None, probe_ids=None
                     ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """Inverted-list recall through the two-stage scan: (scores [nq, k], idx [nq, k], overflow flag [1]).
     Same results as ``knn_search_ivf``; layout arrays from ``ivf2_layout`` + ``bank_shadow_sorted``
     (kept current by ``ivf2_append``).  ``n_sorted``: sorted rows in use (a multiple of 16 that covers
     pad_off[256]; default: all of ``sorted_rows``).  ``lists_flag``: ``ivf2_append``'s flag; if it is
-    set the returned overflow flag carries ``KNN_FLAG_LISTS_STALE``."""
+    set the returned overflow flag carries ``KNN_FLAG_LISTS_STALE``.  ``probe_ids``: ``centroid_probe``'s
+    output for these queries and this centroid table (the probes are then not recomputed)."""
     _need(bank, "bank", torch.float32); _need(inv_norm, "inv_norm", torch.float32)
     _need(meta, "meta", torch.float32); _need(queries, "queries", torch.float32)
     _need(centroids, "centroids", torch.float32); _need(sorted_shadow, "sorted_shadow", torch.bfloat16)
@@ -576,6 +597,16 @@ def knn_search_ivf2(bank, inv_norm, meta, queries, k: int, now: float, centroids
     base = (ws.data_ptr() + 255) // 256 * 256
     if lists_flag is not None:
         _need(lists_flag, "lists_flag", torch.int32)
+    if probe_ids is not None:
+        _need(probe_ids, "probe_ids", torch.int32)
+        if tuple(probe_ids.shape) != (nq, 8):
+            raise ValueError("knn_search_ivf2: probe_ids must be [nq, 8] (centroid_probe)")
+        check(L.aura_knn_search_ivf2_probed(_p(bank), _p(inv_norm), _p(meta), _p(sorted_shadow), _p(rho),
+                                            _p(sorted_rows), _p(pad_off), _p(list_len), _p(lists_flag), ns, M,
+                                            _p(queries), now, D, nq, k, _p(centroids), nprobe, _p(probe_ids),
+                                            idx_base, _p(out_s), _p(out_i), base, nbytes, _p(ovf), _stream()),
+              "aura_knn_search_ivf2_probed")
+        return out_s, out_i, ovf
     check(L.aura_knn_search_ivf2(_p(bank), _p(inv_norm), _p(meta), _p(sorted_shadow), _p(rho), _p(sorted_rows),
                                  _p(pad_off), _p(list_len), _p(lists_flag), ns, M, _p(queries), now, D, nq, k,
                                  _p(centroids), nprobe, idx_base, _p(out_s), _p(out_i), base, nbytes,

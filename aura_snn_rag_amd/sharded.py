@@ -289,15 +289,28 @@ class ShardedHippocampus:
         self._recall_kw = dict(now=self._now() if now is None else now, use_candidates=use_candidates,
                                check_overflow=check_overflow)
         nq = q.shape[0]
+        cand = self.local._candidate_mode() if use_candidates is None else (use_candidates and self.local._candidate_mode())
         if all_gather_queries and self.world > 1:
             # every rank sees every query block: the merged result (and the empty-candidate decision
-            # below) is then identical on all ranks, so the fallback stays collective-safe
-            allq = torch.empty(self.world * nq, q.shape[1], dtype=q.dtype, device=q.device)
-            dist.all_gather_into_tensor(allq, q.contiguous(), group=self.group)
+            # below) is then identical on all ranks, so the fallback stays collective-safe.  The centroid
+            # table is replicated, so each query is probed ONCE, by the rank that brings it, and its probes
+            # ride in the same all-gather as eight extra columns (int32 bits in fp32 lanes).
+            ids = self.local.probe(q) if cand and hasattr(self.local, "probe") else None
+            if ids is not None:
+                payload = torch.cat([q, ids.view(torch.float32)], dim=1).contiguous()
+            else:
+                payload = q.contiguous()
+            # (all ranks take the same branch: index state and device are properties of the sharded bank)
+            allp = torch.empty(self.world * nq, payload.shape[1], dtype=q.dtype, device=q.device)
+            dist.all_gather_into_tensor(allp, payload, group=self.group)
+            if ids is not None:
+                allq = allp[:, :q.shape[1]].contiguous()
+                self._recall_kw["probe_ids"] = allp[:, q.shape[1]:].contiguous().view(torch.int32)
+            else:
+                allq = allp
         else:
             allq = q
         s, r = self._recall.recall(allq, int(k))
-        cand = self.local._candidate_mode() if use_candidates is None else (use_candidates and self.local._candidate_mode())
         # A query is without candidates on EVERY rank only if this rank's flag says so for some query: the
         # host read of the merged result is skipped otherwise (the decision is the same on all ranks whenever
         # such a query exists, so the fallback's collectives stay matched).
@@ -307,6 +320,7 @@ class ShardedHippocampus:
             # no shard had a candidate for these queries: the reference falls back to the full scan (:269-270)
             sel = torch.nonzero(r[:, 0] < 0).flatten()
             self._recall_kw["use_candidates"] = False
+            self._recall_kw.pop("probe_ids", None)
             s2, r2 = self._recall.recall(allq[sel].contiguous(), int(k))
             s[sel], r[sel] = s2, r2
         if allq is not q:

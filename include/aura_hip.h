@@ -258,11 +258,20 @@ int aura_knn_search_shadow(const float* bank, const uint16_t* bank_bf16, const f
  * (bf16 row converted, rho refreshed, pos_of_row updated).  A row whose list has no free entry left is
  * dropped from the lists and *flag |= 1: pass that flag to aura_knn_search_ivf2 as lists_flag (it is
  * reported as AURA_KNN_FLAG_LISTS_STALE) or re-pack after at most `slack` appended rows.
- * aura_knn_search_ivf2: each probed list is streamed once per batch of up to 2048 queries against
- * the queries that probe it; results (rows, score bits) equal aura_knn_search_ivf's.  N = rows of
+ * aura_knn_search_ivf2: each probed list is streamed once per 256 of the queries that probe it, in
+ * passes of up to 8192 queries; results (rows, score bits) equal aura_knn_search_ivf's.  N = rows of
  * the bank (every sorted_rows entry is < N).  D % 8 == 0, D <= 768, k <= 256, nprobe <= 8;
- * overflow_out as in aura_knn_search_ex (non-zero: re-run aura_knn_search_ivf or the masked scan). */
+ * overflow_out as in aura_knn_search_ex (non-zero: re-run aura_knn_search_ivf or the masked scan).
+ * aura_centroid_probe: ids_out[q][p] (p < nprobe, [nq][8] int32) = the p-th nearest of the 256 centroid
+ * rows to query q (L2 on the unnormalised query, ties to the lower row: hippocampal.py:261-262), exactly
+ * what aura_knn_search_ivf2 computes for itself; workspace: aura_centroid_probe_workspace_bytes(nq)
+ * bytes, 256-byte aligned.  aura_knn_search_ivf2_probed takes such ids (of the same queries and
+ * centroid table) instead of recomputing them: a bank sharded over ranks that share one centroid table
+ * probes every query once, on the rank that owns it, not once per rank. */
 int64_t aura_knn_ivf2_workspace_bytes(int64_t n_sorted, int64_t nq, int k);
+int64_t aura_centroid_probe_workspace_bytes(int64_t nq);
+int aura_centroid_probe(const float* centroids, const float* queries, int64_t D, int64_t nq, int nprobe,
+                        int32_t* ids_out, void* workspace, int64_t workspace_bytes, void* stream);
 int aura_bank_shadow_sorted(const float* bank, const float* inv_norm, const int32_t* sorted_rows,
                             uint16_t* sorted_bf16, float* rho, int32_t* pos_of_row, int64_t n_sorted, int64_t D,
                             void* stream);
@@ -276,6 +285,13 @@ int aura_knn_search_ivf2(const float* bank, const float* inv_norm, const float* 
                          const float* centroids, int nprobe, int32_t idx_base, float* out_scores,
                          int32_t* out_idx, void* workspace, int64_t workspace_bytes, int32_t* overflow_out,
                          void* stream);
+int aura_knn_search_ivf2_probed(const float* bank, const float* inv_norm, const float* meta,
+                                const uint16_t* sorted_bf16, const float* rho, const int32_t* sorted_rows,
+                                const int32_t* pad_off, const int32_t* list_len, const int32_t* lists_flag,
+                                int64_t n_sorted, int64_t N, const float* queries, float now, int64_t D, int64_t nq,
+                                int k, const float* centroids, int nprobe, const int32_t* probe_ids, int32_t idx_base,
+                                float* out_scores, int32_t* out_idx, void* workspace, int64_t workspace_bytes,
+                                int32_t* overflow_out, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Surrogate-gradient training path and the prosody-modulated GIF (fp32, [rows][T][H] layout)

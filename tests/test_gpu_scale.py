@@ -252,3 +252,19 @@ def test_large_bank_samples_grow_with_the_bank(dev):
     assert torch.equal(r_m, r_c) and torch.equal(s_m, s_c)
     del hf
     torch.cuda.empty_cache()
+
+
+def test_recall_with_precomputed_probes(bank_1m, dev):
+    """`HippocampalFormation.probe` + `recall_batch(probe_ids=...)` (what a sharded bank does: every query is
+    probed once, by the rank that brings it) returns exactly what the self-probing recall returns; the ids
+    are the 8 nearest centroid rows in distance order."""
+    hf, q, pick, now, host = bank_1m
+    ids = hf.probe(q)
+    assert ids is not None and ids.dtype == torch.int32 and tuple(ids.shape) == (q.shape[0], 8)
+    d = torch.cdist(q[:40].double().cpu(), host["cent"].double())
+    ref = torch.topk(d, 8, dim=1, largest=False).indices
+    agree = (ids[:40].cpu().long() == ref).float().mean().item()
+    assert agree > 0.97, agree                                   # fp32 vs fp64 distances: near-ties may swap
+    s0, r0 = hf.recall_batch(q, k=32, now=now)
+    s1, r1 = hf.recall_batch(q, k=32, now=now, probe_ids=ids)
+    assert torch.equal(r0, r1) and torch.equal(s0, s1)
