@@ -647,3 +647,25 @@ def test_two_stage_ties_and_overflow_fallback(dev):
     s2, i2 = _search(dev, bank2, meta, q2, 20, check_overflow=False)
     assert int(ops._overflow_flag(torch.device(dev)).item()) == 0
     assert i2[0].tolist() == list(range(100, 120))
+
+
+def test_centroid_probe_api(dev):
+    """ops.centroid_probe: ids in distance order, ties to the lower row, columns beyond nprobe stay -1, empty
+    query block; the probes equal what the inverted-list recall computes for itself (same results with and
+    without them)."""
+    from aura_snn_rag_amd import ops
+    g = torch.Generator().manual_seed(3)
+    D = 40
+    cent = torch.randn(256, D, generator=g)
+    cent[100] = cent[7]                                               # an exact tie: the lower row wins
+    q = torch.cat([cent[7:8] + 0.0, torch.randn(300, D, generator=g)]).to(dev).contiguous()
+    cent = cent.to(dev).contiguous()
+    ids = ops.centroid_probe(q, cent, 8)
+    d = torch.cdist(q.double().cpu(), cent.double().cpu())
+    ref = torch.topk(d, 8, dim=1, largest=False).indices
+    assert ids.dtype == torch.int32 and tuple(ids.shape) == (301, 8)
+    assert int(ids[0, 0]) == 7 and int(ids[0, 1]) == 100
+    assert float((ids.cpu().long() == ref).float().mean()) > 0.98
+    ids3 = ops.centroid_probe(q, cent, 3)
+    assert torch.equal(ids3[:, :3], ids[:, :3]) and bool((ids3[:, 3:] == -1).all())
+    assert tuple(ops.centroid_probe(q[:0], cent, 8).shape) == (0, 8)

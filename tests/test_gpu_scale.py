@@ -212,7 +212,8 @@ def test_sharded_bank_on_hip_kernels_two_ranks_one_gpu(dev, tmp_path):
         assert torch.equal(r_o, pr_c[r * 350:(r + 1) * 350])
 
 
-def test_large_bank_samples_grow_with_the_bank(dev):
+@pytest.mark.parametrize("N", [2_500_000, 4_200_000, 6_000_000])     # 64 / 128 / 256 sample tiles per list
+def test_large_bank_samples_grow_with_the_bank(dev, N):
     """A bank well beyond 1 M rows (6 M x 64 here: 1.5 GB): the prefilter's sample grows with the bank --
     128-row groups in the full scan, more sample tiles per inverted list -- so the candidate lists stay
     inside the refine stage's capacity and neither path raises the overflow flag (with the fixed-size
@@ -220,7 +221,7 @@ def test_large_bank_samples_grow_with_the_bank(dev):
     equal the all-fp32 scan / the fp32 lists bit for bit."""
     from aura_snn_rag_amd import ops
     from aura_snn_rag_amd.core.hippocampal import HippocampalFormation
-    N, D, k = 6_000_000, 64, 32
+    D, k = 64, 32
     hf = HippocampalFormation(feature_dim=D, max_memories=N, n_place_cells=8, n_time_cells=4, n_grid_cells=4,
                               device="cuda", use_centroid_index=True)
     g = torch.Generator(device=dev).manual_seed(99)
