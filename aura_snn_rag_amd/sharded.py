@@ -289,13 +289,21 @@ class ShardedHippocampus:
         self._recall_kw = dict(now=self._now() if now is None else now, use_candidates=use_candidates,
                                check_overflow=check_overflow)
         nq = q.shape[0]
-        cand = self.local._candidate_mode() if use_candidates is None else (use_candidates and self.local._candidate_mode())
+        # candidate mode as every rank sees it (index flags + the GLOBAL row count): the collective decisions
+        # below must not depend on what one shard happens to hold
+        loc0 = self.local
+        cand = bool(use_candidates is not False and getattr(loc0, "use_centroid_index", False)
+                    and getattr(loc0, "_index_ready", False) and self.memory_count > loc0.centroids_k)
         if all_gather_queries and self.world > 1:
             # every rank sees every query block: the merged result (and the empty-candidate decision
             # below) is then identical on all ranks, so the fallback stays collective-safe.  The centroid
             # table is replicated, so each query is probed ONCE, by the rank that brings it, and its probes
             # ride in the same all-gather as eight extra columns (int32 bits in fp32 lanes).
-            ids = self.local.probe(q) if cand and hasattr(self.local, "probe") else None
+            # (decided on state every rank shares -- index flags, the GLOBAL row count, the device type --
+            #  so that all ranks gather the same payload shape whatever their own shard holds)
+            loc = self.local
+            probed = cand and loc.centroids.shape[0] == 256 and q.is_cuda and hasattr(self.ops, "centroid_probe")
+            ids = self.ops.centroid_probe(q, loc.centroids, min(8, loc.centroids_k)) if probed else None
             if ids is not None:
                 payload = torch.cat([q, ids.view(torch.float32)], dim=1).contiguous()
             else:
