@@ -542,6 +542,7 @@ class HippocampalFormation(nn.Module):
         on another shard, so the fallback is the caller's decision after the merge).  ``probe_ids``:
         ``probe(queries)`` computed earlier for these queries against the current centroid table (the
         inverted-list path then skips its own probe; other paths ignore it)."""
+        self._last_flag = None                        # set only by a candidate-mode recall that read its flag
         if self.memory_count == 0:
             z = torch.empty(queries.shape[0], 0, device=self.device)
             return z, z.to(torch.int32)
@@ -566,7 +567,6 @@ class HippocampalFormation(nn.Module):
                                   shadow=shadow, rho=self._rho if shadow is not None else None, **kw)
         nprobe = min(8, self.centroids_k)
         scores = rows = ovf = None
-        self._last_flag = None
         full_index = self.centroids.shape[0] == 256
         masked_ok = (q_loc is None and full_index and self.memory_count <= self.MASKED_SCAN_MAX_ROWS and
                      q.shape[0] <= self.MASKED_SCAN_MAX_QUERIES)

@@ -266,6 +266,7 @@ class ShardedHippocampus:
         loc = self.local
         kk = k
         if loc.memory_count == 0:
+            loc._last_flag = None                           # (no recall ran: nothing is known about empty queries)
             s = torch.full((q.shape[0], kk), float("-inf"), device=q.device)
             return s, torch.full((q.shape[0], kk), -1, dtype=torch.int32, device=q.device)
         # one rank: the bank's own empty-candidate fallback (no second host read for the merged result)
