@@ -480,6 +480,12 @@ def main():
             sec["centroid_index_recall_256q"] = {"retrievals_per_s": 256 / dt, "ms_per_step": dt * 1e3}
             dt = timed_wall(lambda: hf.recall_batch(q, k=k, now=now, check_overflow=False), 50)
             sec["centroid_index_recall_no_overflow_read"] = {"retrievals_per_s": nq / dt, "ms_per_step": dt * 1e3}
+            # the query block one rank of an 8-GPU run sees after the all-gather (8 x 2048): passes of 8192
+            g16 = torch.Generator(device=dev).manual_seed(4242)
+            q16 = torch.randn(8 * nq, D, generator=g16, device=dev)
+            dt = timed_wall(lambda: hf.recall_batch(q16, k=k, now=now), 10)
+            sec[f"centroid_index_recall_{8 * nq}q"] = {"retrievals_per_s": 8 * nq / dt, "ms_per_step": dt * 1e3}
+            del q16
             sec["centroid_index_vs_exact"] = dict(planted_half=recall_at(r_c[: nq // 2], r_e[: nq // 2]),
                                                   random_half=recall_at(r_c[nq // 2:], r_e[nq // 2:]),
                                                   note="synthetic Gaussian rows have no cluster structure: the "
