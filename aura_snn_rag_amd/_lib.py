@@ -55,6 +55,8 @@ SIGNATURES = {
     "aura_addition_linear": (I, [P, P, P, P, I64, I64, I64, P]),
     "aura_gif_train_forward": (I, [P, P, P, P, P, P, F, I, F, F, I64, I64, I64, P]),
     "aura_gif_backward": (I, [P, P, P, P, P, P, F, I, F, F, I64, I64, I64, P]),
+    "aura_gif_train_forward_bf16": (I, [P, P, P, P, P, P, F, I, F, F, I64, I64, I64, P]),
+    "aura_gif_backward_bf16": (I, [P, P, P, P, P, P, F, I, F, F, I64, I64, I64, P]),
     "aura_lif_train_forward": (I, [P, P, P, P, P, P, P, I64, I64, P]),
     "aura_lif_backward": (I, [P, P, P, P, P, P, P, P, P, I64, I64, P]),
     "aura_gif_prosody_run": (I, [P, P, P, P, P, F, I, F, F, F, I64, I64, I64, P]),

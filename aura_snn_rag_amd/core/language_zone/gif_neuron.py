@@ -65,8 +65,9 @@ def wants_grad(module: nn.Module, x: torch.Tensor, state=None) -> bool:
 
 
 def _need_fp32_training(x: torch.Tensor, who: str) -> None:
-    if x.dtype != torch.float32:
-        raise NotImplementedError(f"{who}: the surrogate-gradient kernels are fp32; run {x.dtype} "
+    """The GIF loop trains in fp32 and bf16 (``aura_gif_train_forward[_bf16]``); anything else is refused."""
+    if x.dtype not in (torch.float32, torch.bfloat16):
+        raise NotImplementedError(f"{who}: the surrogate-gradient kernels are fp32 / bf16; run {x.dtype} "
                                   f"under torch.no_grad() or train in fp32")
 
 
@@ -97,7 +98,7 @@ class GifLoopFunction(torch.autograd.Function):
 
 
 def run_gif_loop_grad(h: torch.Tensor, state, *, decay: float, L: int, alpha: float, threshold: float):
-    """Autograd-recording twin of ``run_gif_loop`` (fp32, h [rows, T, H])."""
+    """Autograd-recording twin of ``run_gif_loop`` (fp32 or bf16, h [rows, T, H])."""
     rows, _, H = h.shape
     if state is None:
         v = torch.zeros(rows, H, device=h.device, dtype=h.dtype)

@@ -1,5 +1,5 @@
 // aura_train.hip -- surrogate-gradient training kernels and the prosody-modulated GIF loop
-// (SURVEY.md section 8f-4), fp32, channel-contiguous layout [rows][T][H].
+// (SURVEY.md section 8f-4), fp32 (GIF loop: also bf16), channel-contiguous layout [rows][T][H].
 //
 //   GIF   forward (training): the loop of gif_neuron.py:54-69 that also saves, per step, the
 //         pre-clamp potential a_t and the threshold theta_{t-1} it was computed with;
@@ -131,6 +131,141 @@ __global__ __launch_bounds__(256) void gif_bwd_kernel(GifP p, const float* __res
         }
         V<VEC>::st(gv_io + row * C + c0, gv);
         V<VEC>::st(gth_io + row * C + c0, gth);
+    }
+}
+
+// ---- bf16 tensors (the reference under bf16 / autocast): [rows][T][H] of bf16 bit patterns ----
+// Forward: the per-op-rounded loop of aura_gif_run's bf16 form (each op rounds its fp32 result to bf16, Python
+// scalars are fp32) -- spikes and state are bit-identical to it -- saving a_t and theta_{t-1} as the bf16
+// values the reference's graph holds.  Backward: the same BPTT as the fp32 kernel, evaluated in fp32 from
+// those saved bf16 values (the forward intermediates b, d, n, s are recomputed WITH their bf16 roundings, so
+// the surrogate window and the clamp branches are the reference's), gradients carried in fp32 registers
+// across the T steps and rounded to bf16 once, on the way out.  The reference's autograd rounds every
+// intermediate gradient to bf16 instead: its result scatters around this one by a few bf16 ulps per step
+// (tests/test_gpu_training.py compares both).
+__device__ __forceinline__ float rb(float x) { return static_cast<float>(static_cast<__bf16>(x)); }
+__device__ __forceinline__ float bf2f(uint16_t u) { return __uint_as_float((uint32_t)u << 16); }
+__device__ __forceinline__ uint16_t f2bf(float x) {       // round to nearest even (values already bf16: exact)
+    const __bf16 b = static_cast<__bf16>(x);
+    return __builtin_bit_cast(uint16_t, b);
+}
+template <int VEC> struct VB;
+template <> struct VB<8> {
+    __device__ static void ld(const uint16_t* p, float (&x)[8]) {
+        const uint4 t = *reinterpret_cast<const uint4*>(p);
+        const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { x[2 * i] = __uint_as_float(w[i] << 16); x[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+    }
+    __device__ static void st(uint16_t* p, const float (&x)[8]) {
+        uint32_t w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f2bf(x[2 * i]) | ((uint32_t)f2bf(x[2 * i + 1]) << 16);
+        *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+};
+template <> struct VB<1> {
+    __device__ static void ld(const uint16_t* p, float (&x)[1]) { x[0] = bf2f(*p); }
+    __device__ static void st(uint16_t* p, const float (&x)[1]) { *p = f2bf(x[0]); }
+};
+
+// one bf16 GIF step's forward intermediates from (a, theta_prev): b, d, n, s (all bf16 values)
+__device__ __forceinline__ void gif_bf16_mid(const GifP& p, float a, float thp, float& b, float& d, float& n, float& s) {
+    const float cl = rb(rb(p.Lf * thp) * 2.0f);
+    b = fminf(fmaxf(a, -cl), cl);
+    d = rb(thp + 1e-6f);
+    n = rb(b / d);
+    s = fminf(fmaxf(floorf(n), 0.0f), p.Lf);
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void gif_train_fwd_bf16_kernel(GifP p, const uint16_t* __restrict__ h,
+                                                                 uint16_t* __restrict__ spikes, uint16_t* v_io,
+                                                                 uint16_t* th_io, uint16_t* __restrict__ save_a,
+                                                                 uint16_t* __restrict__ save_th, int64_t R,
+                                                                 int64_t T, int64_t C) {
+    const int64_t cv = C / VEC, items = R * cv;
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < items;
+         it += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = it / cv, c0 = (it - row * cv) * VEC;
+        float v[VEC], th[VEC];
+        VB<VEC>::ld(v_io + row * C + c0, v);
+        VB<VEC>::ld(th_io + row * C + c0, th);
+        for (int64_t t = 0; t < T; ++t) {
+            const int64_t o = (row * T + t) * C + c0;
+            float x[VEC], a[VEC], s[VEC], thp[VEC];
+            VB<VEC>::ld(h + o, x);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                thp[e] = th[e];
+                a[e] = rb(rb(v[e] * p.decay) + x[e]);
+                float b, d, n;
+                gif_bf16_mid(p, a[e], th[e], b, d, n, s[e]);
+                v[e] = rb(b - rb(s[e] * th[e]));
+                if (p.alpha > 0.0f)
+                    th[e] = rb(rb(th[e] + rb(p.alpha * s[e])) - rb(p.alpha * rb(th[e] - p.thr0)));
+            }
+            VB<VEC>::st(spikes + o, s);
+            VB<VEC>::st(save_a + o, a);
+            VB<VEC>::st(save_th + o, thp);
+        }
+        VB<VEC>::st(v_io + row * C + c0, v);
+        VB<VEC>::st(th_io + row * C + c0, th);
+    }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void gif_bwd_bf16_kernel(GifP p, const uint16_t* __restrict__ save_a,
+                                                           const uint16_t* __restrict__ save_th,
+                                                           const uint16_t* __restrict__ g_spikes,
+                                                           uint16_t* __restrict__ g_h, uint16_t* gv_io,
+                                                           uint16_t* gth_io, int64_t R, int64_t T, int64_t C) {
+    const int64_t cv = C / VEC, items = R * cv;
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < items;
+         it += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = it / cv, c0 = (it - row * cv) * VEC;
+        float gv[VEC], gth[VEC];
+        VB<VEC>::ld(gv_io + row * C + c0, gv);
+        VB<VEC>::ld(gth_io + row * C + c0, gth);
+        for (int64_t t = T - 1; t >= 0; --t) {
+            const int64_t o = (row * T + t) * C + c0;
+            float a[VEC], thp[VEC], gs[VEC], gh[VEC];
+            VB<VEC>::ld(save_a + o, a);
+            VB<VEC>::ld(save_th + o, thp);
+            VB<VEC>::ld(g_spikes + o, gs);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                float b, d, n, s;
+                gif_bf16_mid(p, a[e], thp[e], b, d, n, s);
+                const float cl = rb(rb(p.Lf * thp[e]) * 2.0f);
+                float gth_prev = gth[e];
+                float gs_tot = gs[e];
+                if (p.alpha > 0.0f) {            // theta_t = (thp + alpha*s) - alpha*(thp - thr0)
+                    gs_tot = gs_tot + p.alpha * gth[e];
+                    gth_prev = gth_prev - p.alpha * gth[e];
+                }
+                gs_tot = gs_tot - thp[e] * gv[e];   // v_t = b - s*thp
+                gth_prev = gth_prev - s * gv[e];
+                float gb = gv[e];
+                const float dist = fabsf(n - rintf(n));
+                const float tri = fminf(fmaxf(1.0f - 2.0f * dist, 0.0f), 1.0f);
+                const float sur = (n >= 0.0f && n <= p.Lf + 1.0f) ? tri : 0.0f;
+                const float gn = gs_tot * sur;
+                gb = gb + gn / d;
+                gth_prev = gth_prev + (-gn * b / (d * d));
+                float ga = 0.0f, gcl = 0.0f;
+                if (a[e] < -cl) gcl = -gb;
+                else if (a[e] > cl) gcl = gb;
+                else ga = gb;
+                gth_prev = gth_prev + gcl * (2.0f * p.Lf);
+                gh[e] = ga;
+                gv[e] = ga * p.decay;
+                gth[e] = gth_prev;
+            }
+            VB<VEC>::st(g_h + o, gh);
+        }
+        VB<VEC>::st(gv_io + row * C + c0, gv);
+        VB<VEC>::st(gth_io + row * C + c0, gth);
     }
 }
 
@@ -411,6 +546,40 @@ int aura_gif_backward(const float* save_a, const float* save_theta, const float*
     const GifP p{decay, (float)L, alpha, threshold};
     AURA_VEC_DISPATCH(gif_bwd_kernel, rows * (H / 4), rows * H, vec, p, save_a, save_theta, g_spikes, g_h,
                       g_v, g_theta, rows, T, H);
+    return check_launch();
+}
+
+int aura_gif_train_forward_bf16(const uint16_t* h, uint16_t* spikes, uint16_t* v, uint16_t* theta, uint16_t* save_a,
+                                uint16_t* save_theta, float decay, int L, float alpha, float threshold,
+                                int64_t rows, int64_t T, int64_t H, void* stream) {
+    if (rows < 0 || T < 0 || H < 0 || L < 0 || L > 256) return AURA_E_INVAL;   // spike counts up to 256 are exact in bf16
+    if (rows == 0 || H == 0) return AURA_OK;
+    if (!v || !theta || (T && (!h || !spikes || !save_a || !save_theta))) return AURA_E_INVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool vec = H % 8 == 0 && aligned16(h) && aligned16(spikes) && aligned16(v) && aligned16(theta) &&
+                     aligned16(save_a) && aligned16(save_theta);
+    const GifP p{decay, (float)L, alpha, threshold};
+    if (vec) hipLaunchKernelGGL((gif_train_fwd_bf16_kernel<8>), dim3(grid_for(rows * (H / 8))), dim3(256), 0, s, p, h,
+                                spikes, v, theta, save_a, save_theta, rows, T, H);
+    else hipLaunchKernelGGL((gif_train_fwd_bf16_kernel<1>), dim3(grid_for(rows * H)), dim3(256), 0, s, p, h, spikes, v,
+                            theta, save_a, save_theta, rows, T, H);
+    return check_launch();
+}
+
+int aura_gif_backward_bf16(const uint16_t* save_a, const uint16_t* save_theta, const uint16_t* g_spikes, uint16_t* g_h,
+                           uint16_t* g_v, uint16_t* g_theta, float decay, int L, float alpha, float threshold,
+                           int64_t rows, int64_t T, int64_t H, void* stream) {
+    if (rows < 0 || T < 0 || H < 0 || L < 0 || L > 256) return AURA_E_INVAL;
+    if (rows == 0 || H == 0) return AURA_OK;
+    if (!g_v || !g_theta || (T && (!save_a || !save_theta || !g_spikes || !g_h))) return AURA_E_INVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool vec = H % 8 == 0 && aligned16(save_a) && aligned16(save_theta) && aligned16(g_spikes) &&
+                     aligned16(g_h) && aligned16(g_v) && aligned16(g_theta);
+    const GifP p{decay, (float)L, alpha, threshold};
+    if (vec) hipLaunchKernelGGL((gif_bwd_bf16_kernel<8>), dim3(grid_for(rows * (H / 8))), dim3(256), 0, s, p, save_a,
+                                save_theta, g_spikes, g_h, g_v, g_theta, rows, T, H);
+    else hipLaunchKernelGGL((gif_bwd_bf16_kernel<1>), dim3(grid_for(rows * H)), dim3(256), 0, s, p, save_a, save_theta,
+                            g_spikes, g_h, g_v, g_theta, rows, T, H);
     return check_launch();
 }
 

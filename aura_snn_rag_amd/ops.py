@@ -144,10 +144,24 @@ def _same_f32(shape, *named) -> None:
             raise ValueError(f"{n}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
 
 
+def _same_dtype(dtype, shape, *named) -> None:
+    for t, n in named:
+        _need(t, n, dtype)
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError(f"{n}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+
+
 def gif_train_forward(h, spikes, v, theta, save_a, save_theta, decay: float, L: int, alpha: float,
                       threshold: float) -> None:
-    """h [rows, T, H] -> spikes, save_a, save_theta [rows, T, H]; v, theta [rows, H] in/out."""
+    """h [rows, T, H] -> spikes, save_a, save_theta [rows, T, H]; v, theta [rows, H] in/out (fp32 or bf16)."""
     rows, T, H = h.shape
+    if h.dtype == torch.bfloat16:
+        _same_dtype(torch.bfloat16, (rows, T, H), (h, "h"), (spikes, "spikes"), (save_a, "save_a"), (save_theta, "save_theta"))
+        _same_dtype(torch.bfloat16, (rows, H), (v, "v"), (theta, "theta"))
+        check(lib().aura_gif_train_forward_bf16(_p(h), _p(spikes), _p(v), _p(theta), _p(save_a), _p(save_theta),
+                                                decay, int(L), alpha, threshold, rows, T, H, _stream()),
+              "aura_gif_train_forward_bf16")
+        return
     _same_f32((rows, T, H), (h, "h"), (spikes, "spikes"), (save_a, "save_a"), (save_theta, "save_theta"))
     _same_f32((rows, H), (v, "v"), (theta, "theta"))
     check(lib().aura_gif_train_forward(_p(h), _p(spikes), _p(v), _p(theta), _p(save_a), _p(save_theta),
@@ -157,8 +171,16 @@ def gif_train_forward(h, spikes, v, theta, save_a, save_theta, decay: float, L: 
 
 def gif_backward(save_a, save_theta, g_spikes, g_h, g_v, g_theta, decay: float, L: int, alpha: float,
                  threshold: float) -> None:
-    """g_v, g_theta [rows, H]: gradients of the final state in, of the initial state out."""
+    """g_v, g_theta [rows, H]: gradients of the final state in, of the initial state out (fp32 or bf16)."""
     rows, T, H = save_a.shape
+    if save_a.dtype == torch.bfloat16:
+        _same_dtype(torch.bfloat16, (rows, T, H), (save_a, "save_a"), (save_theta, "save_theta"),
+                    (g_spikes, "g_spikes"), (g_h, "g_h"))
+        _same_dtype(torch.bfloat16, (rows, H), (g_v, "g_v"), (g_theta, "g_theta"))
+        check(lib().aura_gif_backward_bf16(_p(save_a), _p(save_theta), _p(g_spikes), _p(g_h), _p(g_v), _p(g_theta),
+                                           decay, int(L), alpha, threshold, rows, T, H, _stream()),
+              "aura_gif_backward_bf16")
+        return
     _same_f32((rows, T, H), (save_a, "save_a"), (save_theta, "save_theta"), (g_spikes, "g_spikes"),
               (g_h, "g_h"))
     _same_f32((rows, H), (g_v, "g_v"), (g_theta, "g_theta"))

@@ -313,6 +313,18 @@ int aura_gif_backward(const float* save_a, const float* save_theta, const float*
                       float* g_v, float* g_theta, float decay, int L, float alpha, float threshold,
                       int64_t rows, int64_t T, int64_t H, void* stream);
 
+/* The same pair for bf16 tensors (bit patterns, uint16_t): forward = aura_gif_run's per-op-rounded bf16
+ * loop (bit-identical spikes and state; save_a / save_theta are the bf16 values the reference's graph
+ * holds); backward = the fp32 BPTT evaluated from them with the forward's roundings re-applied to
+ * b, d, n, s, gradients carried in fp32 over the T steps and rounded to bf16 on the way out (the
+ * reference's bf16 autograd rounds every intermediate gradient instead).  L <= 256. */
+int aura_gif_train_forward_bf16(const uint16_t* h, uint16_t* spikes, uint16_t* v, uint16_t* theta,
+                                uint16_t* save_a, uint16_t* save_theta, float decay, int L, float alpha,
+                                float threshold, int64_t rows, int64_t T, int64_t H, void* stream);
+int aura_gif_backward_bf16(const uint16_t* save_a, const uint16_t* save_theta, const uint16_t* g_spikes,
+                           uint16_t* g_h, uint16_t* g_v, uint16_t* g_theta, float decay, int L, float alpha,
+                           float threshold, int64_t rows, int64_t T, int64_t H, void* stream);
+
 /* LIF step for training: spikes, mem_out as aura_lif_run (T = 1) plus pre = beta*mem + x - thr
  * (the surrogate's input), all [B][size]; mem_in is not modified. */
 int aura_lif_train_forward(const float* x, const float* mem_in, const float* beta,

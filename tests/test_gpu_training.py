@@ -97,8 +97,9 @@ def test_gif_module_training_step(dev):
         with torch.no_grad():
             s3, _ = n(x)
         assert not s3.requires_grad and torch.equal(s3, s)
-    with pytest.raises(NotImplementedError):
-        GIFNeuron(8, 8).to(dev).to(torch.bfloat16)(torch.randn(1, 2, 8, device=dev, dtype=torch.bfloat16))
+    # bf16 parameters record autograd too since round 2 (test_gif_bptt_bf16); other dtypes are refused
+    sb, _ = GIFNeuron(8, 8).to(dev).to(torch.bfloat16)(torch.randn(1, 2, 8, device=dev, dtype=torch.bfloat16))
+    assert sb.requires_grad and sb.dtype == torch.bfloat16
 
 
 def test_snnffn_training_path(dev):
@@ -206,3 +207,123 @@ def test_prosody_gif_module(dev, B, T, I, H):
     with pytest.raises(ValueError):
         with torch.no_grad():
             pg(x, attention_gains=gains[:, :-1])
+
+
+def _rb(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def _gif_bf16_bptt_fp32_math(h, v0, t0, ws, wv, wt, decay, L, alpha, thr0):
+    """What aura_gif_backward_bf16 is meant to compute, in torch on the CPU: the bf16 forward (per-op rounding),
+    then BPTT in fp32 from the saved bf16 (a_t, theta_{t-1}) with the forward's roundings re-applied."""
+    rows, T, H = h.shape
+    f = lambda x: x.to(torch.float32)
+    v, th = f(v0), f(t0)
+    A, TH = [], []
+    for t in range(T):
+        a = _rb(_rb(v * decay) + f(h[:, t]))
+        cl = _rb(_rb(L * th) * 2.0)
+        b = torch.minimum(torch.maximum(a, -cl), cl)
+        d = _rb(th + 1e-6)
+        n = _rb(b / d)
+        s = torch.clamp(torch.floor(n), 0, L)
+        A.append(a); TH.append(th)
+        v = _rb(b - _rb(s * th))
+        if alpha > 0:
+            th = _rb(_rb(th + _rb(alpha * s)) - _rb(alpha * _rb(th - thr0)))
+    gv, gth = f(wv).clone(), f(wt).clone()
+    gh = torch.zeros(rows, T, H)
+    for t in range(T - 1, -1, -1):
+        a, thp = A[t], TH[t]
+        cl = _rb(_rb(L * thp) * 2.0)
+        b = torch.minimum(torch.maximum(a, -cl), cl)
+        d = _rb(thp + 1e-6)
+        n = _rb(b / d)
+        s = torch.clamp(torch.floor(n), 0, L)
+        gs = f(ws[:, t]).clone()
+        gthp = gth.clone()
+        if alpha > 0:
+            gs = gs + alpha * gth
+            gthp = gthp - alpha * gth
+        gs = gs - thp * gv
+        gthp = gthp - s * gv
+        gb = gv.clone()
+        tri = torch.clamp(1.0 - 2.0 * (n - torch.round(n)).abs(), 0.0, 1.0)
+        sur = torch.where((n >= 0) & (n <= L + 1.0), tri, torch.zeros_like(tri))
+        gn = gs * sur
+        gb = gb + gn / d
+        gthp = gthp + (-gn * b / (d * d))
+        lo, hi = a < -cl, a > cl
+        ga = torch.where(lo | hi, torch.zeros_like(gb), gb)
+        gcl = torch.where(lo, -gb, torch.where(hi, gb, torch.zeros_like(gb)))
+        gthp = gthp + gcl * (2.0 * L)
+        gh[:, t] = ga
+        gv = ga * decay
+        gth = gthp
+    return gh, gv, gth
+
+
+@pytest.mark.parametrize("rows,T,H,L,alpha", [(7, 12, 64, 8, 0.01), (3, 5, 37, 4, 0.05), (32, 16, 256, 8, 0.0),
+                                              (16, 16, 128, 16, 0.02)])
+def test_gif_bptt_bf16(dev, rows, T, H, L, alpha):
+    """bf16 training path of the GIF loop: the recording forward is the per-op-rounded bf16
+    inference forward bit for bit; the gradients equal the intended arithmetic (fp32 BPTT from the saved bf16
+    values) to one bf16 rounding, and sit within bf16 noise of the reference's own bf16 autograd graph
+    (oracle restatement of gif_neuron.py:54-69 + MultiBitSurrogate on bf16 CPU tensors)."""
+    from aura_snn_rag_amd.core.language_zone.gif_neuron import run_gif_loop, run_gif_loop_grad
+    g = torch.Generator().manual_seed(rows * 31 + T * 5 + H)
+    decay, thr0 = math.exp(-0.1), 1.0
+    bf = torch.bfloat16
+    h = (torch.randn(rows, T, H, generator=g) * 3).to(bf)
+    v0 = (0.4 * torch.randn(rows, H, generator=g)).to(bf)
+    t0 = (1.0 + 0.3 * torch.rand(rows, H, generator=g)).to(bf)
+    ws, wv, wt = (torch.randn(s, generator=g).to(bf) for s in ((rows, T, H), (rows, H), (rows, H)))
+    # HIP
+    hd, vd, td = (x.to(dev).requires_grad_(True) for x in (h, v0, t0))
+    sd, (vT, tT) = run_gif_loop_grad(hd, (vd, td), decay=decay, L=L, alpha=alpha, threshold=thr0)
+    assert sd.dtype == bf and vT.dtype == bf
+    with torch.no_grad():
+        s2, (v2, t2) = run_gif_loop(h.to(dev), (v0.to(dev), t0.to(dev)), decay=decay, L=L, alpha=alpha,
+                                    threshold=thr0, T=T)
+    assert torch.equal(s2, sd) and torch.equal(v2, vT) and torch.equal(t2, tT)
+    got = torch.autograd.grad((sd * ws.to(dev)).sum() + (vT * wv.to(dev)).sum() + (tT * wt.to(dev)).sum(),
+                              [hd, vd, td])
+    assert all(x.dtype == bf for x in got)
+    # (1) the intended arithmetic, to one bf16 rounding of the result
+    want = _gif_bf16_bptt_fp32_math(h, v0, t0, ws, wv, wt, decay, L, alpha, thr0)
+    for a, b, name in zip(got, want, ("g_h", "g_v0", "g_theta0")):
+        a32 = a.float().cpu()
+        err = (a32 - b).abs()
+        tol = 2.0 ** -7 * b.abs() + 1e-6
+        frac = float((err <= tol).float().mean())
+        assert frac > 0.999, f"{name}: {1 - frac:.2e} of the entries beyond one bf16 rounding (max err {err.max():.3e})"
+    # (2) the reference's bf16 autograd graph: same spikes/state, gradients within bf16 noise
+    ho, vo, to = (x.clone().requires_grad_(True) for x in (h, v0, t0))
+    s, v, th = O.gif_run_grad(ho, vo, to, decay, L, alpha, thr0)
+    assert torch.equal(sd.cpu(), s.detach()) and torch.equal(vT.cpu(), v.detach()) and torch.equal(tT.cpu(), th.detach())
+    ref = torch.autograd.grad((s * ws).sum() + (v * wv).sum() + (th * wt).sum(), [ho, vo, to])
+    for a, b, name in zip(got, ref, ("g_h", "g_v0", "g_theta0")):
+        a32, b32 = a.float().cpu().flatten(), b.float().flatten()
+        if float(b32.norm()) == 0.0:
+            assert float(a32.norm()) == 0.0
+            continue
+        cos = float(torch.dot(a32, b32) / (a32.norm() * b32.norm()))
+        rel = float((a32 - b32).norm() / b32.norm())
+        assert cos > 0.995 and rel < 0.08, f"{name}: cosine {cos:.5f}, relative L2 distance {rel:.4f} to the bf16 autograd"
+
+
+def test_gif_module_trains_in_bf16(dev):
+    """GIFNeuron and SNNFFN record autograd for bf16 inputs (they raised NotImplementedError in round 1)."""
+    from aura_snn_rag_amd.core.language_zone.gif_neuron import GIFNeuron
+    from aura_snn_rag_amd.core.language_zone.snn_ffn import SNNFFN
+    torch.manual_seed(0)
+    n = GIFNeuron(32, 64, L=8).to(dev).to(torch.bfloat16)
+    x = torch.randn(4, 6, 32, device=dev, dtype=torch.bfloat16, requires_grad=True)
+    s, (v, th) = n(x)
+    (s.float().mean() + v.float().mean()).backward()
+    assert x.grad is not None and x.grad.dtype == torch.bfloat16 and bool(torch.isfinite(x.grad.float()).all())
+    assert n.linear.weight.grad is not None and float(n.linear.weight.grad.float().abs().sum()) > 0
+    ffn = SNNFFN(32, 64, num_timesteps=4, L=8).to(dev).to(torch.bfloat16).train()
+    y = ffn(torch.randn(2, 5, 32, device=dev, dtype=torch.bfloat16, requires_grad=True))
+    y.float().sum().backward()
+    assert all(p.grad is not None for p in ffn.parameters() if p.requires_grad)
