@@ -1723,6 +1723,21 @@ inline void print_cs_phases(hipStream_t s, const float* buf, int cus) {
                    kmin * 0.01, ksum / n * 0.01, kmax * 0.01, lmin * 0.01, lsum / n * 0.01, lmax * 0.01);
 }
 
+// AURA_CS_DBG bit 128: the refine kernel's phase times and candidate / survivor counts per query
+inline void print_refine_phases(hipStream_t s, const float* buf, int nqb, const char* path) {
+    (void)hipStreamSynchronize(s);
+    std::vector<float> h((size_t)nqb * 8);
+    (void)hipMemcpy(h.data(), buf, h.size() * 4, hipMemcpyDeviceToHost);
+    static const char* const names[6] = {"load candidates", "select T2", "survivors", "load query", "re-score", "rank+write"};
+    double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, mx[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int q = 0; q < nqb; ++q)
+        for (int i = 0; i < 8; ++i) { sum[i] += h[(size_t)q * 8 + i]; if (h[(size_t)q * 8 + i] > mx[i]) mx[i] = h[(size_t)q * 8 + i]; }
+    fprintf(stderr, "[refine phases, %s] %d queries: candidates mean %.0f max %.0f, survivors mean %.0f max %.0f;", path, nqb,
+            sum[6] / nqb, mx[6], sum[7] / nqb, mx[7]);
+    for (int i = 0; i < 6; ++i) fprintf(stderr, " %s %.2f us (max %.2f);", names[i], sum[i] / nqb * 0.01, mx[i] * 0.01);
+    fprintf(stderr, "\n");
+}
+
 // Two-stage recall of one query pass (see aura_knn_coarse.inl).  Returns AURA_OK after queuing
 // sample scan -> threshold -> filter scan -> refine; the caller skips the fp32 pipeline.
 inline int run_coarse_pass(const float* bank, const uint16_t* bank16, const float* rho, const float* inv_norm,
@@ -1829,17 +1844,7 @@ inline int run_coarse_pass(const float* bank, const uint16_t* bank16, const floa
     if ((rc = launch_refine_for(r, nqb, D, cus, s))) return rc;
     if (rtm) {
         --rtm_left;
-        (void)hipStreamSynchronize(s);
-        std::vector<float> h((size_t)nqb * 8);
-        (void)hipMemcpy(h.data(), w.gmax, h.size() * 4, hipMemcpyDeviceToHost);
-        static const char* const names[6] = {"load candidates", "select T2", "survivors", "load query", "re-score", "rank+write"};
-        double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, mx[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int q = 0; q < nqb; ++q)
-            for (int i = 0; i < 8; ++i) { sum[i] += h[(size_t)q * 8 + i]; if (h[(size_t)q * 8 + i] > mx[i]) mx[i] = h[(size_t)q * 8 + i]; }
-        fprintf(stderr, "[refine phases] %d queries: candidates mean %.0f max %.0f, survivors mean %.0f max %.0f;", nqb,
-                sum[6] / nqb, mx[6], sum[7] / nqb, mx[7]);
-        for (int i = 0; i < 6; ++i) fprintf(stderr, " %s %.2f us (max %.2f);", names[i], sum[i] / nqb * 0.01, mx[i] * 0.01);
-        fprintf(stderr, "\n");
+        print_refine_phases(s, w.gmax, nqb, "full scan");
     }
     return check_launch();
 }
@@ -2307,7 +2312,14 @@ static int knn_search_ivf2_impl(const float* bank, const float* inv_norm, const 
             }
             fprintf(stderr, "[ivf2] candidates %ld, invalid %ld\n", tot, bad);
         }
+        static int rtm2_left = 2;                            // AURA_CS_DBG bit 128: refine phase times
+        const bool rtm2 = (cs_dbg & 128) && rtm2_left > 0;
+        if (rtm2) r.dbg_out = w.gmax;
         if ((rc = launch_refine_for(r, nqb, D, cus, s))) return rc;
+        if (rtm2) {
+            --rtm2_left;
+            print_refine_phases(s, w.gmax, nqb, "inverted lists");
+        }
         stage("refine");
     }
     return AURA_OK;

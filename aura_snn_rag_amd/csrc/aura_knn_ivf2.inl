@@ -28,6 +28,8 @@ constexpr int IVF2_STILES_MAX = 256;       // ... and at most
 // stage holds and every call fell back to the fp32 lists -- a power of two in [32, 256].  (At 1 M rows 64
 // tiles instead of 32 cost 35 us more in the sample scan and threshold launches and saved 15 in the refine.)
 static inline int ivf2_stiles(int64_t n_sorted) {
+    static const int forced = getenv("AURA_IVF_STILES") ? atoi(getenv("AURA_IVF_STILES")) : 0;   // tuning runs: 32/64/128/256
+    if (forced == 32 || forced == 64 || forced == 128 || forced == 256) return forced;
     const int64_t avg_tiles = n_sorted / 16 / 256;
     int st = IVF2_STILES;
     while (st < IVF2_STILES_MAX && (int64_t)st * 12 < avg_tiles) st *= 2;
