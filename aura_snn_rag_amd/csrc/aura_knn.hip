@@ -2176,8 +2176,8 @@ static int knn_search_ivf2_impl(const float* bank, const float* inv_norm, const 
     // AURA_IVF_W=s,d overrides (tuning runs); the one-wave-per-SIMD form has a single tile loop.
     static int w_sparse = 0, w_dense = 0;
     if (w_sparse == 0) {
-        int ws = 2, wd = 3;
-        if (const char* e = getenv("AURA_IVF_W")) { if (sscanf(e, "%d,%d", &ws, &wd) != 2 || ws < 1 || wd < 1 || ws > 64 || wd > 64) { ws = 2; wd = 3; } }
+        int ws = 5, wd = 7;
+        if (const char* e = getenv("AURA_IVF_W")) { if (sscanf(e, "%d,%d", &ws, &wd) != 2 || ws < 1 || wd < 1 || ws > 64 || wd > 64) { ws = 5; wd = 7; } }
         if (w4) ws = wd = 1;
         w_dense = wd; w_sparse = ws;
     }

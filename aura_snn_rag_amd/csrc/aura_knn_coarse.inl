@@ -637,9 +637,15 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
 
         auto run_segment = [&](auto NB_, auto RS_) {
         constexpr int NBc = decltype(NB_)::value;           // column blocks (16 queries) per wave
-        constexpr int RS = decltype(RS_)::value;            // 16-row tiles per step (2: row-split form)
-        const int qg = RS == 2 ? (wave & 3) : wave;         // query group: slots [qg * 16 QB, + 16 QB) of the block
-        const int rh = RS == 2 ? (wave >> 2) : 0;           // which tile of the step this wave works on
+        // RS: 1 = one 16-row tile per step; 2 = row-split form (two tiles per step, waves w and w + 4 share
+        // the query slots and take one tile each); 3 = two tiles per step, every wave works on both (blocks
+        // of more than 128 queries in the kernels with the doubled ring: one barrier, one wait and one burst
+        // of DMA issue per 32 rows instead of per 16)
+        constexpr int RS = decltype(RS_)::value;
+        constexpr bool SPLIT = RS == 2;
+        constexpr int TPS = RS == 1 ? 1 : 2;                // tiles per step
+        const int qg = SPLIT ? (wave & 3) : wave;           // query group: slots [qg * 16 QB, + 16 QB) of the block
+        const int rh = SPLIT ? (wave >> 2) : 0;             // row-split: which tile of the step this wave works on
         const int qoff = (int)qblk * 256 + qg * (16 * QB);  // this wave's first query (IVF: block slot)
         int my_cnt = n_used - qg * (16 * QB);
         my_cnt = my_cnt < 0 ? 0 : (my_cnt > 16 * NBc ? 16 * NBc : my_cnt);
@@ -703,9 +709,9 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
         // wait in front of the first pin below then covers fragments and tiles alike
         // step T of the segment = tile j0 + T (RS 1) / tiles j0 + 2T and j0 + 2T + 1 (RS 2; an odd last
         // step streams its one tile twice, so that every step has the same number of pieces in flight)
-        const int64_t n_steps = RS == 2 ? (seg + 1) / 2 : seg;
+        const int64_t n_steps = TPS == 2 ? (seg + 1) / 2 : seg;
         auto issue_step = [&](int64_t T, int ss) {
-            if (RS == 2) {
+            if (TPS == 2) {
                 issue(j0 + 2 * T, 2 * ss);
                 issue(j0 + (2 * T + 1 < seg ? 2 * T + 1 : seg - 1), 2 * ss + 1);
             } else {
@@ -763,11 +769,11 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
             // and the reservation just issued (one instruction when EPL == 1) stay in flight
             if (t + 1 >= n_steps) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             else if (EPL == 1 && fl_n > 0) {
-                if (wave == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(RS * GL + 1) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(RS * NP + 1) : "memory");
+                if (wave == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(TPS * GL + 1) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(TPS * NP + 1) : "memory");
             }
-            else if (wave == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(RS * GL) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(RS * NP) : "memory");
+            else if (wave == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(TPS * GL) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(TPS * NP) : "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             const uint32_t ts1 = stamp();
@@ -782,9 +788,16 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
                     asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(eqr[b]) : "v"(ea), "n"(64 * b) : "memory");
             }
             if (t + 2 < n_steps && !(a.dbg & 4)) issue_step(t + 2, (slot + 2) % NSLOT);
-            const int cslot = RS == 2 ? 2 * slot + rh : slot;       // the 16-row slot this wave computes on
-            const int64_t ctile = RS == 2 ? 2 * t + rh : t;         // ... = tile j0 + ctile of the block
-            const bool work = wave_active && ctile < seg;
+            int cslot = 0;                                          // the 16-row slot this wave computes on
+            int64_t ctile = 0;                                      // ... = tile j0 + ctile of the block
+            bool work = false;
+            auto set_tile = [&](int u) {                            // u-th tile of the step (RS 3); row-split: this wave's
+                const int w = SPLIT ? rh : u;
+                cslot = TPS == 2 ? 2 * slot + w : slot;
+                ctile = TPS == 2 ? 2 * t + w : t;
+                work = wave_active && ctile < seg;
+            };
+            set_tile(0);
 
             auto mma = [&]() {
             if (SRC16) {
@@ -803,7 +816,17 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
             f32x4v xr[PF + 1][2];
             constexpr int RP = SRC16 ? 1 : 2;                // LDS reads per k-step
             constexpr int S_RC = KS >= 3 ? KS - 3 : 0;       // the row constants are fetched behind this step
-            const uint32_t a0 = cs_base + cslot * SLOT_BYTES + off0, a1 = cs_base + cslot * SLOT_BYTES + off1;
+            // (8-wave kernels: the lane's reader offset is recomputed per call, like the loader role in issue() --
+            //  kept live across the tile loop it was spilled, and its reload waits for vmcnt(0))
+            uint32_t o0 = (uint32_t)off0, lgo = (uint32_t)lg * 64u;
+            if (NW == 8 && SRC16) {
+                uint32_t ln3 = (uint32_t)lane;
+                asm volatile("" : "+v"(ln3));
+                const uint32_t lr3 = ln3 & 15u, lg3 = ln3 >> 4;
+                o0 = (4u * lr3 + (lg3 ^ (uint32_t)cs_swz16((int)lr3))) * 16u;
+                lgo = lg3 * 64u;
+            }
+            const uint32_t a0 = cs_base + cslot * SLOT_BYTES + o0, a1 = cs_base + cslot * SLOT_BYTES + off1;
             if (!(a.dbg & 1)) {
             cs_static_for<0, (PF < KS ? PF : KS)>([&](auto S) {
                 constexpr int s = decltype(S)::value;
@@ -843,11 +866,11 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
                 });
                 // the epilogue's row constants are fetched behind the last two k-steps
                 if constexpr (s == S_RC)
-                    lds_read4x16_nowait(cs_base + cslot * SLOT_BYTES + TILE_BYTES + lg * 64, rcv[0], rcv[1], rcv[2], rcv[3]);
+                    lds_read4x16_nowait(cs_base + cslot * SLOT_BYTES + TILE_BYTES + lgo, rcv[0], rcv[1], rcv[2], rcv[3]);
                 __builtin_amdgcn_sched_barrier(0);
             });
             } else {
-                lds_read4x16_nowait(cs_base + cslot * SLOT_BYTES + TILE_BYTES + lg * 64, rcv[0], rcv[1], rcv[2], rcv[3]);
+                lds_read4x16_nowait(cs_base + cslot * SLOT_BYTES + TILE_BYTES + lgo, rcv[0], rcv[1], rcv[2], rcv[3]);
             }
             lds_wait4(rcv[0], rcv[1], rcv[2], rcv[3]);
             __builtin_amdgcn_sched_barrier(0);
@@ -986,8 +1009,8 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
             const uint32_t ts4 = stamp();
             if (MODE == CS_MODE_FILTER && fl_n > 0) {       // second step of the write-out (wave-uniform)
                 if (t + 2 >= n_steps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                else if (wave == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RS * GL) : "memory");   // reservations are older
-                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RS * NP) : "memory");
+                else if (wave == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TPS * GL) : "memory");   // reservations are older
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TPS * NP) : "memory");
                 const uint32_t eb = wreg_addr + (par ^ 1) * (WCAP * 12);
 #pragma unroll
                 for (int u = 0; u < EPL; ++u) {
@@ -1005,6 +1028,10 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
 
             const uint32_t ts5 = stamp();
             if (work) epi(ctile);
+            if (RS == 3) {                                          // the step's second tile, same wave
+                set_tile(1);
+                if (work) { mma(); epi(ctile); }
+            }
             if (tm) {
                 const uint32_t ts6 = stamp();
                 tacc[0] += ts1 - ts0; tacc[1] += ts2 - ts1; tacc[2] += ts3 - ts2;
@@ -1020,6 +1047,7 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
         }
         };
         if (SP32 && QB == 2 && n_used <= 128 && !(a.dbg & 256)) run_segment(std::integral_constant<int, QB>{}, std::integral_constant<int, 2>{});
+        else if (SP32 && QB == 2 && !(a.dbg & 1024)) run_segment(std::integral_constant<int, QB>{}, std::integral_constant<int, 3>{});
         else run_segment(std::integral_constant<int, QB>{}, std::integral_constant<int, 1>{});
         // segment end: the stream has drained and every wave is done with the block's LDS tables.  Buffered
         // candidates carry their query and bank row, so they stay where they are until the buffer fills or
