@@ -66,12 +66,13 @@ SIGNATURES = {
     "aura_knn_search_shadow": (I, [P, P, P, P, P, P, F, I64, I64, I64, I, I32, P, P, P, I64, I, P, P, I, P]),
     "aura_knn_ivf2_workspace_bytes": (I64, [I64, I64, I]),
     "aura_bank_shadow_sorted": (I, [P, P, P, P, P, P, I64, I64, P]),
-    "aura_ivf2_append": (I, [P, P, P, P, I64, I64, P, P, P, P, P, P, P, P]),
-    "aura_knn_search_ivf2": (I, [P, P, P, P, P, P, P, P, P, I64, I64, P, F, I64, I64, I, P, I, I32, P, P, P, I64, P, P]),
+    "aura_ivf2_append": (I, [P, P, P, P, I64, I64, P, P, P, P, P, P, P, P, F, P]),
+    "aura_ivf2_row_constants": (I, [P, P, P, I64, I64, F, P, P]),
+    "aura_knn_search_ivf2": (I, [P, P, P, P, P, P, P, P, P, P, I64, I64, P, F, I64, I64, I, P, I, I32, P, P, P, I64, P, P]),
     "aura_centroid_probe_workspace_bytes": (I64, [I64]),
     "aura_centroid_probe": (I, [P, P, I64, I64, I, P, P, I64, P]),
-    "aura_knn_search_ivf2_probed": (I, [P, P, P, P, P, P, P, P, P, I64, I64, P, F, I64, I64, I, P, I, P, I32, P, P, P, I64,
-                                        P, P]),
+    "aura_knn_search_ivf2_probed": (I, [P, P, P, P, P, P, P, P, P, P, I64, I64, P, F, I64, I64, I, P, I, P, I32, P, P, P,
+                                        I64, P, P]),
     "aura_profile_begin": (I, [I]),
     "aura_profile_end": (I, [P, I]),
     "aura_profile_last_scan": (I, [P, P]),

@@ -91,9 +91,15 @@ class _IvfState:
         self.list_len = torch.zeros(256, dtype=torch.int32, device=device)
         self.pos_of_row = torch.full((max_rows,), -1, dtype=torch.int32, device=device)
         self.flag = torch.zeros(1, dtype=torch.int32, device=device)
-        self.n_sorted = 16            # sorted rows in use (host-side bound, a multiple of 16)
+        self.n_sorted = 16            # sorted rows in use (host-side bound, a multiple of 16; fixed between re-packs)
         self.appended = 0             # rows appended since the last re-pack
         self.valid = False
+        # cached score constants of the sorted rows (aura_ivf2_row_constants): valid for ONE fp32 `now` (the
+        # reference's fp32 timestamps give time a 128-second grain) while metadata, rho and layout are unchanged
+        self.rowc: Optional[torch.Tensor] = None
+        self.rowc_live = False
+        self.rowc_now = 0.0           # the fp32 `now` the table was built for
+        self.rowc_version = -1        # memory_metadata._version it was built from (catches in-place edits by the user)
 
 
 class HippocampalFormation(nn.Module):
@@ -166,6 +172,7 @@ class HippocampalFormation(nn.Module):
         self.register_buffer('centroids', torch.zeros(self.centroids_k, feature_dim, device=dev))
         self.register_buffer('centroid_counts', torch.zeros(self.centroids_k, device=dev))
         self._index_ready = False
+        self._last_flag = None                    # overflow flag of the last candidate-mode recall that read it
         # inverted lists of the centroid index, derived from memory_metadata[:, 2]:
         self._ivf: Optional[_IvfState] = None     # list-sorted bf16 shadow, kept current by the writes
         self._ivf_pending = None                  # (order, seg_off) left by rebuild_centroids for the next re-pack
@@ -272,14 +279,31 @@ class HippocampalFormation(nn.Module):
             st.n_sorted = min(st.n_alloc, ops.ivf2_alloc_rows(n, slack))
             st.pos_of_row.fill_(-1)
             st.flag.zero_()
+            st.rowc_live = False
             ops.bank_shadow_sorted(self.memory_features, self._inv_norm, st.sorted_rows, st.sorted_bf16, rho,
                                    st.pos_of_row, st.n_sorted)
             st.appended = 0
             st.valid = True
         return st
 
-    def _ivf_after_write(self, uniq_slots: torch.Tensor, n_rows: int) -> None:
-        """Append the rows just written to their lists (their centroid ids are in the metadata)."""
+    def _ivf_row_constants(self, st: _IvfState, now: float) -> torch.Tensor:
+        """The sorted rows' score constants for ``now``, rebuilt only when ``now`` (as fp32), the metadata or
+        the list layout changed since the last call (31 us per call at 1 M rows otherwise)."""
+        nowf = float(np.float32(now))
+        if st.rowc is None or st.rowc.device != st.sorted_rows.device:
+            st.rowc = torch.empty(st.n_alloc, 4, dtype=torch.float32, device=st.sorted_rows.device)
+            st.rowc_live = False
+        ver = self.memory_metadata._version
+        if not (st.rowc_live and st.rowc_now == nowf and st.rowc_version == ver):
+            ops.ivf2_row_constants(self.memory_metadata, self._rho, st.sorted_rows, st.n_sorted,
+                                   self.memory_features.shape[1], nowf, st.rowc)
+            st.rowc_live, st.rowc_now, st.rowc_version = True, nowf, ver
+        return st.rowc
+
+    def _ivf_after_write(self, uniq_slots: torch.Tensor, n_rows: int, meta_v0: Optional[int] = None) -> None:
+        """Append the rows just written to their lists (their centroid ids are in the metadata).
+        ``meta_v0``: ``memory_metadata._version`` before the write touched it (the cached score constants
+        follow the write only if nobody else edited the metadata since they were built)."""
         st = self._ivf
         if st is None or not st.valid:
             return
@@ -290,10 +314,14 @@ class HippocampalFormation(nn.Module):
         if self._rho is None or st.appended + n_rows > max(st.slack, self.memory_count // 8):
             st.valid = False
             return
+        live = st.rowc is not None and st.rowc_live and meta_v0 is not None and st.rowc_version == meta_v0
         ops.ivf2_append(self.memory_features, self._inv_norm, self.memory_metadata, uniq_slots, st.sorted_bf16,
-                        st.sorted_rows, st.pad_off, st.list_len, st.pos_of_row, self._rho, st.flag)
+                        st.sorted_rows, st.pad_off, st.list_len, st.pos_of_row, self._rho, st.flag,
+                        row_constants=st.rowc if live else None, row_constants_now=st.rowc_now)
         st.appended += n_rows
-        st.n_sorted = min(st.n_alloc, ops.ivf2_alloc_rows(self.memory_count, st.slack))
+        st.rowc_live = live
+        st.rowc_version = self.memory_metadata._version
+        # (n_sorted stays what the re-pack set: pad_off is fixed until the next one, so no list reaches beyond it)
 
     def _apply(self, fn, *a, **k):  # keep self.device / current_location in step with .to()
         out = super()._apply(fn, *a, **k)
@@ -379,7 +407,8 @@ class HippocampalFormation(nn.Module):
             return None
         return np.sort(slots.size - 1 - first_rev)
 
-    def _after_write(self, slot_t: torch.Tensor, uniq_t: torch.Tensor, slots: np.ndarray, c0: int, n_app: int) -> None:
+    def _after_write(self, slot_t: torch.Tensor, uniq_t: torch.Tensor, slots: np.ndarray, c0: int, n_app: int,
+                     meta_v0: Optional[int] = None) -> None:
         """Derived state after a write: the appended run [c0, c0 + n_app) and the overwritten slots."""
         if n_app and self._norms_valid_upto >= c0:     # the kernel refreshed 1/||row|| of the written slots
             self._norms_valid_upto = max(self._norms_valid_upto, c0 + n_app)
@@ -392,7 +421,7 @@ class HippocampalFormation(nn.Module):
                     self._shadow_after_write(over, int(slots[n_app:].min()), int(slots[n_app:].max()), contiguous=False)
         self._lists_dirty = True
         self._ivf_pending = None
-        self._ivf_after_write(uniq_t, int(uniq_t.numel()))
+        self._ivf_after_write(uniq_t, int(uniq_t.numel()), meta_v0)
 
     def _write_rows(self, ids: Sequence[str], feats: torch.Tensor, now: float) -> None:
         """Write a run of rows that contains no centroid-rebuild boundary."""
@@ -423,6 +452,7 @@ class HippocampalFormation(nn.Module):
     def _store_rows(self, ids, feats, slots: np.ndarray, n_app: int, new_count: int, new_cursor: int, now: float,
                     online: bool, cids: Optional[torch.Tensor] = None) -> None:
         c0 = self.memory_count
+        meta_v0 = self.memory_metadata._version
         slot_t = torch.from_numpy(slots).to(self.device)
         eff_k = min(self.centroids_k, self.centroids.shape[0])
         # A batch that overwrites may name a slot more than once (a full bank in the reference's mode
@@ -446,7 +476,7 @@ class HippocampalFormation(nn.Module):
             c = cids.to(device=self.device, dtype=torch.float32)
             self.memory_metadata[uniq_t, 2] = c if keep is None else c[keep_t]
         self.memory_count, self._write_cursor = new_count, new_cursor
-        self._after_write(slot_t, uniq_t, slots, c0, n_app)
+        self._after_write(slot_t, uniq_t, slots, c0, n_app, meta_v0)
         self._slot_time[slots] = time.time()
         slot_list = slots.tolist()
         self.id_to_idx.update(zip(ids, slot_list))
@@ -478,13 +508,14 @@ class HippocampalFormation(nn.Module):
         if n <= 0:
             return 0
         s0 = self.memory_count
+        meta_v0 = self.memory_metadata._version
         slot_t = torch.arange(s0, s0 + n, dtype=torch.int64, device=self.device)
         ops.bank_write(self.memory_features, self.memory_locations, self.memory_metadata,
                        self._inv_norm, feats[:n].contiguous(), slot_t,
                        self.current_location.to(device=self.device, dtype=torch.float32).contiguous(),
                        time.time())
         self.memory_count = s0 + n
-        self._after_write(slot_t, slot_t, np.arange(s0, s0 + n, dtype=np.int64), s0, n)
+        self._after_write(slot_t, slot_t, np.arange(s0, s0 + n, dtype=np.int64), s0, n, meta_v0)
         self._slot_time[s0:s0 + n] = time.time()
         self._implicit_ids.append((s0, s0 + n, id_prefix, first_index))
         if rebuild and self.use_centroid_index and self.memory_count > self.centroids_k:
@@ -529,7 +560,7 @@ class HippocampalFormation(nn.Module):
                      locations: Optional[torch.Tensor] = None, now: Optional[float] = None,
                      use_candidates: Optional[bool] = None, check_overflow: bool = True,
                      fallback_empty: bool = True,
-                     probe_ids: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+                     probe_ids: Optional[torch.Tensor] = None, _retry: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
         """Batched recall: ``(scores [nq, k'], rows [nq, k'])`` with ``k' = min(k, count)``;
         rows are bank row indices (int32), ``-1`` where a query has fewer than ``k'`` candidates.
 
@@ -591,16 +622,19 @@ class HippocampalFormation(nn.Module):
                                                         q, kk, now, self.centroids, nprobe, ivf.sorted_bf16,
                                                         self._rho, ivf.sorted_rows, ivf.pad_off, ivf.list_len,
                                                         n_sorted=ivf.n_sorted, lists_flag=ivf.flag,
-                                                        probe_ids=probe_ids)
+                                                        probe_ids=probe_ids,
+                                                        row_constants=self._ivf_row_constants(ivf, now))
         if check_overflow and scores is not None:
             # ONE host read for both conditions: the library's flag carries the overflow bits of the
             # two-stage lists and the "a query has no candidate at all" bit
             f = int(ovf.item())
             if f & ops.KNN_FLAG_LISTS_STALE:          # a write outgrew a list's slack: re-pack, then once more
                 self._ivf.valid = False
-                return self.recall_batch(queries, k=k, locations=locations, now=now, use_candidates=use_candidates,
-                                         check_overflow=check_overflow, fallback_empty=fallback_empty,
-                                         probe_ids=probe_ids)
+                if _retry < 2:
+                    return self.recall_batch(queries, k=k, locations=locations, now=now, use_candidates=use_candidates,
+                                             check_overflow=check_overflow, fallback_empty=fallback_empty,
+                                             probe_ids=probe_ids, _retry=_retry + 1)
+                f |= 1                                # a fresh re-pack that is stale again: never loop, use the fp32 lists
             if f & ~ops.KNN_FLAG_NO_CANDIDATES:
                 scores = rows = None                  # candidate lists too long: the fp32 paths below
             elif not (f & ops.KNN_FLAG_NO_CANDIDATES) or not fallback_empty:
@@ -700,6 +734,8 @@ class HippocampalFormation(nn.Module):
         if self.memory_count == 0:
             return
         ops.bank_decay(self.memory_metadata, float(decay_rate), self.memory_count)
+        if self._ivf is not None:
+            self._ivf.rowc_live = False                 # strengths changed under the cached score constants
 
     def decay(self, rate: float = 0.01) -> None:
         self.decay_memories(decay_rate=rate)

@@ -19,6 +19,8 @@
 
 namespace {
 
+#include "aura_rowc.inl"
+
 typedef float f32x8b __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8b __attribute__((ext_vector_type(8)));
 
@@ -109,7 +111,8 @@ __global__ __launch_bounds__(256) void ivf2_append_kernel(const float* __restric
                                                           const int32_t* __restrict__ pad_off,
                                                           int32_t* __restrict__ list_len,
                                                           int32_t* __restrict__ pos_of_row,
-                                                          float* __restrict__ rho, int32_t* __restrict__ flag) {
+                                                          float* __restrict__ rho, int32_t* __restrict__ flag,
+                                                          float4* __restrict__ rowc, float rowc_now) {
     const int lane = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= n) return;
@@ -117,7 +120,10 @@ __global__ __launch_bounds__(256) void ivf2_append_kernel(const float* __restric
     int pos = -1;
     if (lane == 0) {
         const int old = pos_of_row[slot];
-        if (old >= 0) sorted_rows[old] = -1;
+        if (old >= 0) {
+            sorted_rows[old] = -1;
+            if (rowc) rowc[old] = ivf2_row_constants(-1, meta, rho, rowc_now, (float)D);
+        }
         const int c = (int)meta[slot * 4 + 2];
         if (c >= 0 && c < 256) {
             const int p = atomicAdd(&list_len[c], 1);
@@ -134,7 +140,15 @@ __global__ __launch_bounds__(256) void ivf2_append_kernel(const float* __restric
     pos = __shfl(pos, 0);
     if (pos < 0) return;
     const float r = shadow_convert_row(bank + slot * D, inv_norm[slot], sorted_bf16 + (int64_t)pos * D, D, lane);
-    if (lane == 0) rho[slot] = r;
+    if (lane == 0) {
+        rho[slot] = r;
+        // the caller's cached score constants (aura_ivf2_row_constants) follow the new entry
+        if (rowc) {
+            const float4 m = *reinterpret_cast<const float4*>(meta + slot * 4);
+            rowc[pos] = coarse_row_constants(m, 0.0f, &r, rowc_now, aura_e_fix((float)D), 0.0f, coarse_eq_worst((float)D),
+                                             __int_as_float((int32_t)slot));
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -282,8 +296,10 @@ int aura_bank_shadow_sorted(const float* bank, const float* inv_norm, const int3
 
 int aura_ivf2_append(const float* bank, const float* inv_norm, const float* meta, const int64_t* slots,
                      int64_t n, int64_t D, uint16_t* sorted_bf16, int32_t* sorted_rows, const int32_t* pad_off,
-                     int32_t* list_len, int32_t* pos_of_row, float* rho, int32_t* flag, void* stream) {
+                     int32_t* list_len, int32_t* pos_of_row, float* rho, int32_t* flag, float* row_constants,
+                     float row_constants_now, void* stream) {
     if (n < 0 || D <= 0 || (D & 7)) return AURA_E_INVAL;
+    if (reinterpret_cast<uintptr_t>(row_constants) & 15) return AURA_E_ALIGN;
     if (n == 0) return AURA_OK;
     if (!bank || !inv_norm || !meta || !slots || !sorted_bf16 || !sorted_rows || !pad_off || !list_len ||
         !pos_of_row || !rho || !flag)
@@ -291,7 +307,8 @@ int aura_ivf2_append(const float* bank, const float* inv_norm, const float* meta
     if ((reinterpret_cast<uintptr_t>(bank) & 15) || (reinterpret_cast<uintptr_t>(sorted_bf16) & 15)) return AURA_E_ALIGN;
     hipLaunchKernelGGL(ivf2_append_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), bank, inv_norm, meta, slots, n, D, sorted_bf16, sorted_rows,
-                       pad_off, list_len, pos_of_row, rho, flag);
+                       pad_off, list_len, pos_of_row, rho, flag, reinterpret_cast<float4*>(row_constants),
+                       row_constants_now);
     return check_launch_b();
 }
 

@@ -38,6 +38,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4v_t __attribute__((ext_vector_type(4)));
 
 inline int check_launch() { return hipGetLastError() == hipSuccess ? AURA_OK : AURA_E_LAUNCH; }
 inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
@@ -842,34 +843,48 @@ __global__ __launch_bounds__(SCAN_THREADS) void knn_scan_filter_v2(const ScanArg
 // ------------------------------------------------------------------------------------------
 // Centroid probe: for each query the `nprobe` nearest (L2, unnormalised query) of the 256
 // centroid rows -> 256-bit mask (+ ids in distance order).  hippocampal.py:261-262: the topk runs
-// over ALL 256 buffer rows, also the zero rows beyond centroids_k.  Two kernels:
-//   centroid_dist_kernel : dist[q][c] = sqrt(sum_d (c_d - q_d)^2), 8 queries x 64 centroids per
-//                          workgroup, 32-deep k-chunks through LDS with register prefetch
-//   probe_select_kernel  : per query, nprobe rounds of a 256-wide argmin (ties -> lower centroid)
-// (The first version did the distances one wave per centroid row inside the per-query workgroup:
-// 252 us for 256 queries; this split takes ~20 us.)
+// over ALL 256 buffer rows, also the zero rows beyond centroids_k.
+//
+// One fused kernel (round 3; rounds 1-2: a VALU distance kernel, 43 us per 2048 queries, and a
+// 256-thread argmin kernel, 25 us).  For a fixed query, ||c - q||^2 = ||q||^2 + (||c||^2 - 2 q.c), so the
+// ranking key is ||c||^2 - 2 q.c: the query's own norm -- 768 for a Gaussian query, where the key is O(10)
+// -- never enters, which makes the key MORE accurate in fp32 than the direct sum of 768 squares.  q.c runs
+// on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulation).
+//   workgroup = 16 queries x 256 centroids, 4 waves; wave w owns centroids [64 w, 64 w + 64) as four
+//   16 x 16 output tiles.  Lane (r = lane & 15, h = lane >> 4) loads 16 bytes of query row r and of
+//   centroid rows 16 t + r at k = 16 j + 4 h: element m of those loads is the lane's A / B value of the
+//   j-th group's m-th MFMA (any k permutation is fine as long as A and B use the same one).  ||c||^2
+//   falls out of the same loads (the lane's partial over its k, summed over the four h lanes).
+//   Keys go to LDS; then 16 lanes per query hold 16 keys each and run `nprobe` rounds of
+//   (local argmin, 4-step butterfly), ties to the lower centroid; the winner leaves through an alive mask.
+//   The per-list query lists of the inverted-list recall (lq_cnt / lq_list, optional) are filled here:
+//   one returning atomic per probe on the list's counter (zeroed by the caller); the order inside a
+//   list is whatever the atomics make it (results do not depend on it).
 // ------------------------------------------------------------------------------------------
-constexpr int PD_Q = 8, PD_C = 64;
-constexpr int PD_BK = 128;                 // k-chunk per barrier pair (was 32: 48 barriers per launch
-constexpr int PD_STRIDE = PD_BK + 4;       // made the 0.1 GFLOP kernel take 30 us); 132-float rows keep
-                                           // the per-lane ds_read_b128 of 64 rows conflict-free
+constexpr int PR_Q = 16;                   // queries per workgroup
+constexpr int PR_KSTRIDE = 260;            // floats per key row in LDS (260 % 32 = 4: the four query groups of a
+                                           // wave read different banks)
 
-__global__ __launch_bounds__(256) void centroid_dist_kernel(const float* __restrict__ centroids,
-                                                            const float* __restrict__ queries,
-                                                            int64_t D, int nq,
-                                                            float* __restrict__ dist) {
-    __shared__ __attribute__((aligned(16))) float Cs[PD_C * PD_STRIDE];
-    __shared__ __attribute__((aligned(16))) float Qs[PD_Q * PD_STRIDE];
-    const int tid = threadIdx.x;
-    const int c0 = blockIdx.x * PD_C, q0 = blockIdx.y * PD_Q;
-    const int cl = tid & 63, qs = (tid >> 6) * 2;      // this thread: centroid cl x queries qs, qs+1
-    // staging: a row chunk is 32 float4; thread -> (row r0 + 8 i, float4 column tid & 31)
-    const int r0 = tid >> 5, col = (tid & 31) * 4;
-    const bool vec = (D & 3) == 0;
-    auto ld = [&](const float* base, int64_t k0) {
+__global__ __launch_bounds__(256) void centroid_probe_kernel(const float* __restrict__ centroids,
+                                                             const float* __restrict__ queries,
+                                                             int64_t D, int nq, int nprobe,
+                                                             uint32_t* __restrict__ mask_out,
+                                                             int32_t* __restrict__ ids_out,
+                                                             int32_t* __restrict__ lq_cnt,
+                                                             int32_t* __restrict__ lq_list, int lq_stride) {
+    __shared__ float s_key[PR_Q * PR_KSTRIDE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, h = lane >> 4;
+    const int q0 = blockIdx.x * PR_Q;
+    const int c0 = wave * 64;
+    const bool vec = (D & 3) == 0 && ((reinterpret_cast<uintptr_t>(queries) | reinterpret_cast<uintptr_t>(centroids)) & 15) == 0;
+    const int qrow = q0 + r < nq ? q0 + r : nq - 1;          // rows beyond nq repeat the last query (never written)
+    const float* const qp = queries + (int64_t)qrow * D;
+    const float* cp[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) cp[t] = centroids + (int64_t)(c0 + 16 * t + r) * D;
+    auto ld = [&](const float* base, int64_t k) -> float4 {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (!base) return v;
-        const int64_t k = k0 + col;
         if (vec) { if (k < D) v = *reinterpret_cast<const float4*>(base + k); }
         else {
             if (k + 0 < D) v.x = base[k + 0];
@@ -879,93 +894,101 @@ __global__ __launch_bounds__(256) void centroid_dist_kernel(const float* __restr
         }
         return v;
     };
-    const float* qb = q0 + r0 < nq ? queries + (int64_t)(q0 + r0) * D : nullptr;   // rows 0..7 = all 256 threads
-    float4 pc[8], pq;
+    f32x4v_t acc[4];
+    float cn[4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) pc[i] = ld(centroids + (int64_t)(c0 + r0 + 8 * i) * D, 0);
-    pq = ld(qb, 0);
-    float acc0 = 0.0f, acc1 = 0.0f;
-    for (int64_t k0 = 0; k0 < D; k0 += PD_BK) {
+    for (int t = 0; t < 4; ++t) { acc[t] = f32x4v_t{0.f, 0.f, 0.f, 0.f}; cn[t] = 0.0f; }
+    float4 a = ld(qp, 4 * h), b[4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(Cs + (r0 + 8 * i) * PD_STRIDE + col) = pc[i];
-        *reinterpret_cast<float4*>(Qs + r0 * PD_STRIDE + col) = pq;
-        __syncthreads();
-        if (k0 + PD_BK < D) {
+    for (int t = 0; t < 4; ++t) b[t] = ld(cp[t], 4 * h);
+    for (int64_t k0 = 0; k0 < D; k0 += 16) {
+        float4 an = make_float4(0.f, 0.f, 0.f, 0.f), bn[4];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) pc[i] = ld(centroids + (int64_t)(c0 + r0 + 8 * i) * D, k0 + PD_BK);
-            pq = ld(qb, k0 + PD_BK);
+        for (int t = 0; t < 4; ++t) bn[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k0 + 16 < D) {                                   // next group's loads fly during the 16 MFMAs
+            an = ld(qp, k0 + 16 + 4 * h);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) bn[t] = ld(cp[t], k0 + 16 + 4 * h);
         }
-#pragma unroll 8
-        for (int j = 0; j < PD_BK / 4; ++j) {           // zero-padded beyond D: (0 - 0)^2 adds nothing
-            const float4 c = *reinterpret_cast<const float4*>(Cs + cl * PD_STRIDE + 4 * j);
-            const float4 a = *reinterpret_cast<const float4*>(Qs + qs * PD_STRIDE + 4 * j);
-            const float4 b = *reinterpret_cast<const float4*>(Qs + (qs + 1) * PD_STRIDE + 4 * j);
-            float d;
-            d = c.x - a.x; acc0 = fmaf(d, d, acc0);  d = c.y - a.y; acc0 = fmaf(d, d, acc0);
-            d = c.z - a.z; acc0 = fmaf(d, d, acc0);  d = c.w - a.w; acc0 = fmaf(d, d, acc0);
-            d = c.x - b.x; acc1 = fmaf(d, d, acc1);  d = c.y - b.y; acc1 = fmaf(d, d, acc1);
-            d = c.z - b.z; acc1 = fmaf(d, d, acc1);  d = c.w - b.w; acc1 = fmaf(d, d, acc1);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            cn[t] = fmaf(b[t].x, b[t].x, cn[t]); cn[t] = fmaf(b[t].y, b[t].y, cn[t]);
+            cn[t] = fmaf(b[t].z, b[t].z, cn[t]); cn[t] = fmaf(b[t].w, b[t].w, cn[t]);
         }
-        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[t].x, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[t].y, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[t].z, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[t].w, acc[t], 0, 0, 0);
+        }
+        a = an;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) b[t] = bn[t];
     }
-    if (q0 + qs < nq) dist[(int64_t)(q0 + qs) * 256 + c0 + cl] = sqrtf(acc0);
-    if (q0 + qs + 1 < nq) dist[(int64_t)(q0 + qs + 1) * 256 + c0 + cl] = sqrtf(acc1);
-}
-
-// lq_cnt / lq_list (optional): the per-list query lists of the inverted-list recall, filled here (one
-// returning atomic per probe on the list's counter, zeroed by the caller) instead of by a one-workgroup
-// pass over all (query, probe) pairs afterwards; the order inside a list is whatever the atomics make it
-// (results do not depend on it).
-__global__ __launch_bounds__(256) void probe_select_kernel(const float* __restrict__ dist, int nprobe,
-                                                           uint32_t* __restrict__ mask_out,
-                                                           int32_t* __restrict__ ids_out,
-                                                           int32_t* __restrict__ lq_cnt,
-                                                           int32_t* __restrict__ lq_list, int lq_stride) {
-    __shared__ float s_bv[4];
-    __shared__ int s_bi[4];
-    __shared__ uint32_t s_m[8];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float mine = dist[(int64_t)blockIdx.x * 256 + tid];
-    if (tid < 8) s_m[tid] = 0u;
-    __syncthreads();
-    for (int p = 0; p < nprobe; ++p) {
-        float bv = mine;
-        int bi = tid;
+    // ||c||^2 of centroid c0 + 16 t + r: the four h lanes hold its partials
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
+    for (int t = 0; t < 4; ++t) {
+        cn[t] += __shfl_xor(cn[t], 16);
+        cn[t] += __shfl_xor(cn[t], 32);
+    }
+    // C/D layout: lane -> centroid column r, query rows 4 h + e
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            s_key[(4 * h + e) * PR_KSTRIDE + c0 + 16 * t + r] = fmaf(-2.0f, acc[t][e], cn[t]);
+    __syncthreads();
+
+    // ---- selection: 16 lanes per query (query 4 wave + h of the workgroup), lane r holds centroids r + 16 m ----
+    const int ql = 4 * wave + h;
+    const int q = q0 + ql;
+    float kv[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) kv[m] = s_key[ql * PR_KSTRIDE + r + 16 * m];
+    uint32_t alive = 0xffffu;
+    uint32_t mword = 0u;                                     // lane r < 8: word r of the query's 256-bit mask
+    int my_id = -1;                                          // lane r < 8: the r-th nearest centroid
+    for (int p = 0; p < nprobe; ++p) {
+        float bv = INFINITY;
+        int bi = 0x7fff;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            const bool take = ((alive >> m) & 1u) && (bi == 0x7fff || kv[m] < bv);
+            bv = take ? kv[m] : bv;
+            bi = take ? r + 16 * m : bi;
+        }
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) {
             const float ov = __shfl_xor(bv, off);
             const int oi = __shfl_xor(bi, off);
-            if (ov < bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            if (oi != 0x7fff && (bi == 0x7fff || ov < bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
         }
-        if (lane == 0) { s_bv[wave] = bv; s_bi[wave] = bi; }
-        __syncthreads();
-        bv = s_bv[0]; bi = s_bi[0];
-#pragma unroll
-        for (int w = 1; w < 4; ++w)
-            if (s_bv[w] < bv || (s_bv[w] == bv && s_bi[w] < bi)) { bv = s_bv[w]; bi = s_bi[w]; }
-        if (tid == bi) {
-            mine = INFINITY;
-            s_m[bi >> 5] |= 1u << (bi & 31);
-            if (ids_out && p < 8) ids_out[(int64_t)blockIdx.x * 8 + p] = bi;
-            if (lq_cnt && p < 8) {
-                const int slot = atomicAdd(&lq_cnt[bi], 1);
-                if (slot < lq_stride) lq_list[(int64_t)bi * lq_stride + slot] = ((int)blockIdx.x << 4) | p;
+        if (bi == 0x7fff) break;                             // nothing left (nprobe > 256 never happens; NaN rows)
+        if ((bi & 15) == r) alive &= ~(1u << (bi >> 4));
+        if ((bi >> 5) == r) mword |= 1u << (bi & 31);
+        if (p == r) my_id = bi;
+    }
+    if (q < nq && r < 8) {
+        mask_out[(int64_t)q * 8 + r] = mword;
+        if (my_id >= 0) {
+            if (ids_out) ids_out[(int64_t)q * 8 + r] = my_id;
+            if (lq_cnt) {
+                const int slot = atomicAdd(&lq_cnt[my_id], 1);
+                if (slot < lq_stride) lq_list[(int64_t)my_id * lq_stride + slot] = (q << 4) | r;
             }
         }
-        __syncthreads();
     }
-    if (tid < 8) mask_out[(int64_t)blockIdx.x * 8 + tid] = s_m[tid];
 }
 
-// probe = distances + selection; dist_ws: nq*256 floats of scratch
+// probe = keys + selection in one launch (dist_ws: unused since round 3, kept in the workspace layout)
 inline int launch_probe(const float* centroids, const float* queries, int64_t D, int nq, int nprobe,
                         float* dist_ws, uint32_t* mask_out, int32_t* ids_out, hipStream_t s,
                         int32_t* lq_cnt = nullptr, int32_t* lq_list = nullptr, int lq_stride = 0) {
-    hipLaunchKernelGGL(centroid_dist_kernel, dim3(256 / PD_C, (unsigned)((nq + PD_Q - 1) / PD_Q)),
-                       dim3(256), 0, s, centroids, queries, D, nq, dist_ws);
-    if (hipGetLastError() != hipSuccess) return AURA_E_LAUNCH;
-    hipLaunchKernelGGL(probe_select_kernel, dim3((unsigned)nq), dim3(256), 0, s, dist_ws, nprobe,
-                       mask_out, ids_out, lq_cnt, lq_list, lq_stride);
+    (void)dist_ws;
+    if (nq <= 0) return AURA_OK;
+    hipLaunchKernelGGL(centroid_probe_kernel, dim3((unsigned)((nq + PR_Q - 1) / PR_Q)), dim3(256), 0, s,
+                       centroids, queries, D, nq, nprobe, mask_out, ids_out, lq_cnt, lq_list, lq_stride);
     return hipGetLastError() == hipSuccess ? AURA_OK : AURA_E_LAUNCH;
 }
 
@@ -1770,7 +1793,7 @@ inline int run_coarse_pass(const float* bank, const uint16_t* bank16, const floa
     const int64_t nq_pad = ((int64_t)nqb + 255) / 256 * 256;
     // error bound of the bf16 scores (aura_knn_coarse.inl): E_fix for the accumulation, E_worst for
     // rows rounded on the fly; with the shadow the rows' and queries' own residual norms
-    const float e_fix = 2.0f * (float)D * 5.9604645e-8f + 1e-5f;
+    const float e_fix = aura_e_fix((float)D);
     const float e_cos = 0.0078125f * (1.0f + 0.001953125f) + e_fix;
     // the shadow is only usable when its rows are 16-byte aligned and its error norms are known
     const bool use16 = bank16 && rho && (D & 7) == 0 && (reinterpret_cast<uintptr_t>(bank16) & 15) == 0;
@@ -2139,7 +2162,7 @@ static int knn_search_ivf2_impl(const float* bank, const float* inv_norm, const 
                          int64_t D, int64_t nq, int k,
                          const float* centroids, int nprobe, int32_t idx_base, float* out_scores,
                          int32_t* out_idx, void* workspace, int64_t workspace_bytes,
-                         int32_t* overflow_out, const int32_t* probe_ids, void* stream) {
+                         int32_t* overflow_out, const int32_t* probe_ids, const float4* rowc_cached, void* stream) {
     if (n_sorted <= 0 || N <= 0 || N > 0x7ffffff0LL || D <= 0 || D > 768 || (D & 7) || nq < 0 || k <= 0 ||
         k > COARSE_MAX_K)
         return AURA_E_INVAL;
@@ -2157,7 +2180,7 @@ static int knn_search_ivf2_impl(const float* bank, const float* inv_norm, const 
     if (w.bytes > workspace_bytes) return AURA_E_INVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int KS = D <= 256 ? 8 : (D <= 512 ? 16 : 24);
-    const float e_fix = 2.0f * (float)D * 5.9604645e-8f + 1e-5f;   // see aura_knn_coarse.inl
+    const float e_fix = aura_e_fix((float)D);                // see aura_knn_coarse.inl
     const int cus = device_cu_count();
     int rc;
     // AURA_IVF2_TRACE: synchronise after every stage and name it on stderr (to localise a device fault)
@@ -2181,21 +2204,29 @@ static int knn_search_ivf2_impl(const float* bank, const float* inv_norm, const 
         if (w4) ws = wd = 1;
         w_dense = wd; w_sparse = ws;
     }
-    // The sorted rows' score constants depend on `now` and the bank only: one launch per call, not per
-    // pass.  (Measured dead end: the same launch on a side stream, forked and joined with events so that it
-    // runs beside the probe / plan launches -- 0.80 vs 0.78 ms per 2048-query call, the two event
+    // The sorted rows' score constants depend on `now` and the bank only: the caller may keep them across
+    // calls (rowc_cached, aura_ivf2_row_constants; 31 us per call at 1 M rows otherwise), else one launch per
+    // call, not per pass.  (Measured dead end: the same launch on a side stream, forked and joined with events
+    // so that it runs beside the probe / plan launches -- 0.80 vs 0.78 ms per 2048-query call, the two event
     // creations and the cross-stream waits cost more than the 35 us they hide.)
-    hipLaunchKernelGGL(ivf2_prep_kernel, dim3((unsigned)((n_sorted + 255) / 256)), dim3(256), 0, s,
-                       queries, (int64_t)0, D, KS, w.lq_cnt, w.lq_list, w.blk_off, w.blk_list, w.nblk, w.qhat,
-                       w.inv_q, w.slotq, w.qslot, w.thr, nullptr, lists_flag, w.eq_slot, w.eq_q,
-                       0, meta, rho, sorted_rows, n_sorted, now, e_fix, w.rowc);
-    if ((rc = check_launch())) return rc;
+    const float4* rowc = rowc_cached;
+    if (!rowc) {
+        hipLaunchKernelGGL(ivf2_rowc_kernel, dim3((unsigned)((n_sorted + 255) / 256)), dim3(256), 0, s,
+                           meta, rho, sorted_rows, n_sorted, now, (float)D, w.rowc);
+        if ((rc = check_launch())) return rc;
+        rowc = w.rowc;
+    }
     for (int64_t qb0 = 0; qb0 < nq; qb0 += w.qp) {
         const int nqb = (int)((nq - qb0) < w.qp ? (nq - qb0) : w.qp);
         const float* qptr = queries + qb0 * D;
+        // per query: 1/||q||, bf16 fragments, eq; resets of the pass (per-list counters, qslot, the call's flag)
+        hipLaunchKernelGGL(ivf2_qprep_kernel, dim3((unsigned)((nqb + 1 + 3) / 4)), dim3(256), 0, s,
+                           qptr, (int64_t)nqb, D, KS, w.qhat, w.inv_q, w.eq_q, w.qslot, w.lq_cnt,
+                           qb0 == 0 ? overflow_out : nullptr, lists_flag);
+        if ((rc = check_launch())) return rc;
+        stage("query prep");
         // the probe launch also fills the per-list query lists (lq_cnt / lq_list); probes that the caller
         // already has (a sharded bank computes them once per query, not once per rank) only fill the lists
-        if (hipMemsetAsync(w.lq_cnt, 0, 256 * 4, s) != hipSuccess) return AURA_E_LAUNCH;
         if (probe_ids) {
             hipLaunchKernelGGL(ivf2_lists_from_ids_kernel, dim3((unsigned)((nqb * 8 + 255) / 256)), dim3(256), 0, s,
                                probe_ids + qb0 * 8, nqb, nprobe, w.lq_cnt, w.lq_list);
@@ -2208,17 +2239,15 @@ static int knn_search_ivf2_impl(const float* bank, const float* inv_norm, const 
                            stiles, w_sparse, w_dense);
         if ((rc = check_launch())) return rc;
         stage("plan");
-        const int qblocks = ivf2_maxblk(w.qp) * 256 / 4;      // query slots only (the rows' part ran above)
-        hipLaunchKernelGGL(ivf2_prep_kernel, dim3((unsigned)qblocks), dim3(256), 0, s,
-                           qptr, (int64_t)nqb, D, KS, w.lq_cnt, w.lq_list, w.blk_off, w.blk_list, w.nblk, w.qhat,
-                           w.inv_q, w.slotq, w.qslot, w.thr, qb0 == 0 ? overflow_out : nullptr, lists_flag, w.eq_slot, w.eq_q,
-                           qblocks, meta, rho, sorted_rows, n_sorted, now, e_fix, w.rowc);
+        hipLaunchKernelGGL(ivf2_slots_kernel, dim3((unsigned)ivf2_maxblk(w.qp)), dim3(256), 0, s,
+                           w.lq_cnt, w.lq_list, w.blk_off, w.blk_list, w.nblk, w.eq_q, w.slotq, w.qslot, w.thr,
+                           w.eq_slot);
         if ((rc = check_launch())) return rc;
-        stage("prep");
+        stage("slots");
 
         CoarseArgs c{};
-        c.bank = bank; c.bank16 = sorted_bf16; c.rowc = w.rowc; c.qhat = w.qhat; c.inv_q = w.inv_q;
-        c.eq = w.eq_slot;
+        c.bank = bank; c.bank16 = sorted_bf16; c.rowc = rowc; c.qhat = w.qhat; c.inv_q = w.inv_q;
+        c.eq = w.eq_slot; c.qzero = nqb;
         c.N = n_sorted; c.D = D; c.nq = ivf2_maxblk(w.qp) * 256;
         c.thr = w.thr; c.cnt = w.cnt; c.cand_scores = w.cand_scores; c.cand_idx = w.cand_idx; c.cap = w.cap;
         c.blk_row0 = w.blk_row0; c.blk_stride = w.blk_stride; c.nblk = w.nblk; c.slotq = w.slotq;
@@ -2325,29 +2354,47 @@ static int knn_search_ivf2_impl(const float* bank, const float* inv_norm, const 
     return AURA_OK;
 }
 
+int aura_ivf2_row_constants(const float* meta, const float* rho, const int32_t* sorted_rows, int64_t n_sorted,
+                            int64_t D, float now, float* row_constants, void* stream) {
+    if (n_sorted < 0 || n_sorted > 0x7ffffff0LL || D <= 0) return AURA_E_INVAL;
+    if (n_sorted == 0) return AURA_OK;
+    if (!meta || !rho || !sorted_rows || !row_constants) return AURA_E_INVAL;
+    if ((reinterpret_cast<uintptr_t>(meta) & 15) || (reinterpret_cast<uintptr_t>(row_constants) & 15)) return AURA_E_ALIGN;
+    hipLaunchKernelGGL(ivf2_rowc_kernel, dim3((unsigned)((n_sorted + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), meta, rho, sorted_rows, n_sorted, now, (float)D,
+                       reinterpret_cast<float4*>(row_constants));
+    return check_launch();
+}
+
 int aura_knn_search_ivf2(const float* bank, const float* inv_norm, const float* meta,
                          const uint16_t* sorted_bf16, const float* rho, const int32_t* sorted_rows, const int32_t* pad_off,
-                         const int32_t* list_len, const int32_t* lists_flag, int64_t n_sorted, int64_t N,
+                         const int32_t* list_len, const int32_t* lists_flag, const float* row_constants,
+                         int64_t n_sorted, int64_t N,
                          const float* queries, float now, int64_t D, int64_t nq, int k,
                          const float* centroids, int nprobe, int32_t idx_base, float* out_scores,
                          int32_t* out_idx, void* workspace, int64_t workspace_bytes,
                          int32_t* overflow_out, void* stream) {
+    if (reinterpret_cast<uintptr_t>(row_constants) & 15) return AURA_E_ALIGN;
     return knn_search_ivf2_impl(bank, inv_norm, meta, sorted_bf16, rho, sorted_rows, pad_off, list_len, lists_flag,
                                 n_sorted, N, queries, now, D, nq, k, centroids, nprobe, idx_base, out_scores, out_idx,
-                                workspace, workspace_bytes, overflow_out, nullptr, stream);
+                                workspace, workspace_bytes, overflow_out, nullptr,
+                                reinterpret_cast<const float4*>(row_constants), stream);
 }
 
 int aura_knn_search_ivf2_probed(const float* bank, const float* inv_norm, const float* meta,
                                 const uint16_t* sorted_bf16, const float* rho, const int32_t* sorted_rows,
                                 const int32_t* pad_off, const int32_t* list_len, const int32_t* lists_flag,
+                                const float* row_constants,
                                 int64_t n_sorted, int64_t N, const float* queries, float now, int64_t D, int64_t nq,
                                 int k, const float* centroids, int nprobe, const int32_t* probe_ids, int32_t idx_base,
                                 float* out_scores, int32_t* out_idx, void* workspace, int64_t workspace_bytes,
                                 int32_t* overflow_out, void* stream) {
     if (!probe_ids) return AURA_E_INVAL;
+    if (reinterpret_cast<uintptr_t>(row_constants) & 15) return AURA_E_ALIGN;
     return knn_search_ivf2_impl(bank, inv_norm, meta, sorted_bf16, rho, sorted_rows, pad_off, list_len, lists_flag,
                                 n_sorted, N, queries, now, D, nq, k, centroids, nprobe, idx_base, out_scores, out_idx,
-                                workspace, workspace_bytes, overflow_out, probe_ids, stream);
+                                workspace, workspace_bytes, overflow_out, probe_ids,
+                                reinterpret_cast<const float4*>(row_constants), stream);
 }
 
 int aura_knn_search(const float* bank, const float* inv_norm, const float* meta, const float* loc,

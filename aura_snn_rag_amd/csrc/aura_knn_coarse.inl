@@ -46,6 +46,8 @@
 //     global_load_lds ring and candidates are buffered in LDS and flushed per span.
 // Traffic: the bank once (N D 4 bytes) + 20 B of row constants per row.
 
+#include "aura_rowc.inl"
+
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef float f32x8v __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
@@ -109,6 +111,9 @@ struct CoarseArgs {
     const int32_t* nblk;     // [1]
     const int32_t* slotq;    // [nblk * 256]
     const int32_t* blk_nq;   // [nblk] query slots in use in block B (the rest of its 256 are padding)
+    int qzero;               // IVF: qhat holds ONE fragment set per QUERY ([q][KS][4 k-groups][8], written once per
+                             // query whatever the number of lists it probes); a lane finds its slot's query through
+                             // slotq, unused slots read the all-zero entry qzero
     int w_sparse, w_dense;   // IVF filter: item_off counts tiles x these weights (block of <= 128 / more queries)
     int dbg;                 // AURA_CS_DBG timing ablations (results invalid when non-zero)
 };
@@ -312,29 +317,7 @@ __device__ __forceinline__ void mfma_bf16_q(f32x4v& acc, const bf16x8v& af, cons
 __device__ __forceinline__ float coarse_eq_from_e2(float e2, float D) {
     return (1.001f * sqrtf(e2) + (0.5f * D + 3.0f) * 5.9604645e-8f) * 1.0078125f;
 }
-__host__ __device__ __forceinline__ float coarse_eq_worst(float D) {
-    return (1.001f * 0.00390625f * 1.00001f + (0.5f * D + 3.0f) * 5.9604645e-8f) * 1.0078125f;
-}
-
-// Per-row score constants {A, B_up, B_lo, w} of the two-stage path (w: centroid id / bank row id).
-//   rho != NULL (normalised bf16 shadow rows): A = 0.5 strength, the row's error part from rho[row];
-//   rho == NULL (fp32 rows rounded on the fly): A = 0.5 strength / ||row||, worst-case error e_worst.
-__device__ __forceinline__ float4 coarse_row_constants(const float4 m, float inv_norm_row, const float* rho_row,
-                                                       float now, float e_fix, float e_worst, float eq_worst,
-                                                       float w) {
-    const float strength = m.x;
-    const float tw = 0.2f * expf(-(now - m.y) / 3600.0f);
-    float A, err;
-    if (rho_row) {
-        A = 0.5f * strength;
-        err = 0.5f * fabsf(strength) * (*rho_row + e_fix);
-        if (strength < 0.0f) err += fabsf(strength) * eq_worst;     // 2 |A| eq_worst
-    } else {
-        A = 0.5f * inv_norm_row * strength;
-        err = 0.5f * e_worst * fabsf(strength);
-    }
-    return make_float4(A, tw * strength + err, tw * strength - err, w);
-}
+// (coarse_eq_worst, coarse_row_constants: aura_rowc.inl)
 
 // Per-call preparation for the two-stage path, one launch:
 //   blocks [0, qblocks): 4 queries each (one wave per query): 1/||q|| (as query_prep_kernel), the
@@ -685,19 +668,24 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
             }
 #pragma unroll
             for (int b = 0; b < NBc; ++b) thrf[b] = qoff + 16 * b + lr < a.nq ? ord_unkey(key[b]) : INFINITY;
-#pragma unroll
-            for (int b = 0; b < NBc; ++b) qid[b] = IVF ? a.slotq[qoff + 16 * b + lr] : 0;
         } else {
 #pragma unroll
             for (int b = 0; b < NBc; ++b) thrf[b] = INFINITY;
         }
 #pragma unroll
+        for (int b = 0; b < NBc; ++b) qid[b] = IVF ? a.slotq[qoff + 16 * b + lr] : 0;
+#pragma unroll
         for (int b = 0; b < NBc; ++b) {                     // (a column block without a query is never multiplied)
-            const uint16_t* qp = a.qhat + (((qblk * 16 + qg * QB + b) * KS) * 64 + lane) * 8;
+            // full scan: fragments laid out by slot, a fragment is one coalesced 1-KiB wave load; inverted lists:
+            // one fragment set per query, the lane's 16 bytes of k-step s sit at [query][s][lg] (64 B per query
+            // and k-step, all KS steps of a query contiguous)
+            const uint16_t* qp = IVF ? a.qhat + ((int64_t)(qid[b] >= 0 ? qid[b] : a.qzero) * (KS * 4) + lg) * 8
+                                     : a.qhat + (((qblk * 16 + qg * QB + b) * KS) * 64 + lane) * 8;
+            constexpr int QSTEP = IVF ? 32 : 512;           // uint16 elements between k-steps
             if (b < nb || NBc != 2) {
 #pragma unroll
                 for (int s = 0; s < KS; ++s)
-                    qf[b][s] = *reinterpret_cast<const bf16x8v*>(qp + (int64_t)s * 512);
+                    qf[b][s] = *reinterpret_cast<const bf16x8v*>(qp + (int64_t)s * QSTEP);
             } else {
 #pragma unroll
                 for (int s = 0; s < KS; ++s)

@@ -44,6 +44,13 @@ static inline int ivf2_maxblk(int64_t qp) { return 256 + (int)((qp * 8 + 255) / 
 constexpr int IVF2_MAXBLK = 256 + IVF2_MAXQ * 8 / 256;
 static_assert(IVF2_MAXBLK == IVF2_MAXBLK_C, "coarse_scan_kernel's block search covers IVF2_MAXBLK_C prefixes");
 
+// queries probing list c: the per-list query list holds IVF2_MAXQ entries, a counter beyond that (caller-made
+// probe ids that repeat a list) is clamped everywhere it is read
+__device__ __forceinline__ int ivf2_list_queries(const int32_t* __restrict__ lq_cnt, int c) {
+    const int n = lq_cnt[c];
+    return n < IVF2_MAXQ ? n : IVF2_MAXQ;
+}
+
 // ---- plan: blocks, their row ranges and the work-item prefixes (one workgroup) ----
 __global__ __launch_bounds__(256) void ivf2_plan_kernel(const int32_t* __restrict__ lq_cnt,
                                                         const int32_t* __restrict__ pad_off,   // [257] first sorted row of each list
@@ -60,7 +67,8 @@ __global__ __launch_bounds__(256) void ivf2_plan_kernel(const int32_t* __restric
                                                         int w_sparse, int w_dense) {   // cost of a tile of a block of <= 128 / more queries
     __shared__ int s_nb[257];
     const int tid = threadIdx.x;
-    s_nb[tid + 1] = (lq_cnt[tid] + 255) / 256;
+    const int my_cnt = ivf2_list_queries(lq_cnt, tid);
+    s_nb[tid + 1] = (my_cnt + 255) / 256;
     if (tid == 0) s_nb[0] = 0;
     __syncthreads();
     for (int off = 1; off < 256; off <<= 1) {              // inclusive scan of s_nb[1..256]
@@ -75,7 +83,7 @@ __global__ __launch_bounds__(256) void ivf2_plan_kernel(const int32_t* __restric
     for (int b = s_nb[tid]; b < s_nb[tid + 1]; ++b) {
         blk_list[b] = tid;
         blk_row0[b] = pad_off[tid];
-        const int left = lq_cnt[tid] - (b - s_nb[tid]) * 256;
+        const int left = my_cnt - (b - s_nb[tid]) * 256;
         blk_nq[b] = left < 256 ? left : 256;
         blk_stride[b] = tiles > stiles ? tiles / stiles : 1;   // sample tiles j * stride, j < stiles
     }
@@ -88,7 +96,7 @@ __global__ __launch_bounds__(256) void ivf2_plan_kernel(const int32_t* __restric
     __shared__ int s_it[257], s_st[257];
     const int nb = s_nb[tid + 1] - s_nb[tid];
     const int stl = tiles < stiles ? tiles : stiles;
-    const int last_left = lq_cnt[tid] - (nb - 1) * 256;
+    const int last_left = my_cnt - (nb - 1) * 256;
     const int w_last = last_left <= 128 ? w_sparse : w_dense;
     s_it[tid + 1] = nb > 0 ? tiles * ((nb - 1) * w_dense + w_last) : 0; s_st[tid + 1] = nb * stl;
     if (tid == 0) { s_it[0] = 0; s_st[0] = 0; }
@@ -116,108 +124,106 @@ __global__ __launch_bounds__(256) void ivf2_lists_from_ids_kernel(const int32_t*
     if (q >= nq || p >= nprobe) return;
     const int c = ids[t];
     if ((unsigned)c >= 256u) return;                       // not a centroid row: the probe is dropped
+    for (int p2 = 0; p2 < p; ++p2)                         // a list named twice by one query is scanned once
+        if (ids[q * 8 + p2] == c) return;
     const int slot = atomicAdd(&lq_cnt[c], 1);
     if (slot < IVF2_MAXQ) lq_list[(int64_t)c * IVF2_MAXQ + slot] = (q << 4) | p;
 }
 
-// ---- prep: per block slot the query's bf16 fragments, the slot <-> query maps, +inf thresholds;
-//      per sorted row the score constants (with the bank row id's bits in .w) ----
-__global__ __launch_bounds__(256) void ivf2_prep_kernel(const float* __restrict__ x, int64_t nq, int64_t D, int KS,
-                                                        const int32_t* __restrict__ lq_cnt,
-                                                        const int32_t* __restrict__ lq_list,   // [256][IVF2_MAXQ]
-                                                        const int32_t* __restrict__ blk_off,
-                                                        const int32_t* __restrict__ blk_list,
-                                                        const int32_t* __restrict__ nblk,
-                                                        uint16_t* __restrict__ qhat, float* __restrict__ inv,
-                                                        int32_t* __restrict__ slotq, int32_t* __restrict__ qslot,
-                                                        uint32_t* __restrict__ thr, int32_t* overflow,
-                                                        const int32_t* __restrict__ lists_flag,
-                                                        float* __restrict__ eq_slot, float* __restrict__ eq_q,
-                                                        int qblocks, const float* __restrict__ meta,
-                                                        const float* __restrict__ rho,
-                                                        const int32_t* __restrict__ sorted_rows, int64_t Npad,
-                                                        float now, float e_fix, float4* __restrict__ rowc) {
-    if ((int)blockIdx.x >= qblocks) {
-        const int64_t i = ((int64_t)blockIdx.x - qblocks) * 256 + threadIdx.x;
-        if (i >= Npad) return;
-        const int32_t row = sorted_rows[i];
-        if (row < 0) {                                    // padding row: can never reach a threshold
-            rowc[i] = make_float4(0.0f, -INFINITY, -INFINITY, __int_as_float(-1));
-            return;
-        }
-        const float4 m = *reinterpret_cast<const float4*>(meta + (int64_t)row * 4);
-        rowc[i] = coarse_row_constants(m, 0.0f, rho + row, now, e_fix, 0.0f, coarse_eq_worst((float)D),
-                                       __int_as_float(row));
-        return;
-    }
+// ---- per-query prep (one wave per query): 1/||q|| (query_prep_kernel's arithmetic), the normalised query as
+//      bf16 fragments [q][KS][4 k-groups][8] -- ONE set per query, whatever the number of lists it probes; the
+//      scan's lanes find their slot's query through slotq (rounds 1-2 wrote one set per (query, probe) slot:
+//      25 MB per 2048 queries, 31 us) -- its part eq of the error bound, and the pass's resets: qslot = -1,
+//      the per-list counters, the call's flag, the all-zero entry nq that unused slots read ----
+__global__ __launch_bounds__(256) void ivf2_qprep_kernel(const float* __restrict__ x, int64_t nq, int64_t D, int KS,
+                                                         uint16_t* __restrict__ qfrag, float* __restrict__ inv,
+                                                         float* __restrict__ eq_q, int32_t* __restrict__ qslot,
+                                                         int32_t* __restrict__ lq_cnt, int32_t* overflow,
+                                                         const int32_t* __restrict__ lists_flag) {
     const int lane = threadIdx.x & 63;
-    const int64_t vs = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);     // virtual slot = B * 256 + slot
-    // reset of the call's flag; bit 7: aura_ivf2_append dropped a row because a list had no slack left
-    if (overflow && blockIdx.x == 0 && threadIdx.x == 0)
-        *overflow = (lists_flag && *lists_flag) ? AURA_KNN_FLAG_LISTS_STALE : 0;
-    const int B = (int)(vs >> 8);
-    if (B >= nblk[0]) return;
-    const int list = blk_list[B];
-    const int ls = (B - blk_off[list]) * 256 + (int)(vs & 255);           // slot inside the list's query list
-    const bool used = ls < lq_cnt[list];
-    int q = -1, p = 0;
-    if (used) {
-        const int packed = lq_list[(int64_t)list * IVF2_MAXQ + ls];
-        q = packed >> 4; p = packed & 15;
+    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (blockIdx.x == 0) {
+        lq_cnt[threadIdx.x] = 0;
+        // reset of the call's flag; bit 7: aura_ivf2_append dropped a row because a list had no slack left
+        if (overflow && threadIdx.x == 0) *overflow = (lists_flag && *lists_flag) ? AURA_KNN_FLAG_LISTS_STALE : 0;
     }
-    if (lane == 0) {
-        slotq[vs] = q;
-        thr[vs] = 0xff800000u;                             // ord_key(+inf): nothing passes until the
-        if (used) qslot[(int64_t)q * 8 + p] = (int32_t)vs; // threshold kernel lowers it
-    }
-    // Slots are filled in order, and the scan multiplies a wave's column blocks only if the wave holds a
-    // query (coarse_scan_kernel; a wave is 32 or 64 slots): a 64-slot group without any query is never
-    // read, so its 96 KB of fragments are not written -- about half of this kernel's writes at 8 probes x
-    // 2048 queries over 256 lists.  Unused slots INSIDE a group that is read get zeros, as before: an
-    // accumulator of a padding column must stay finite (+inf would pass its +inf threshold).
-    if ((ls & ~63) >= lq_cnt[list]) {
-        if (lane == 0) eq_slot[vs] = 0.0f;
+    if (q > nq) return;
+    uint16_t* const base = qfrag + q * (int64_t)KS * 32;
+    if (q == nq) {                                          // the zero entry
+        for (int c = lane; c < KS * 4; c += 64) *reinterpret_cast<uint4*>(base + c * 8) = make_uint4(0u, 0u, 0u, 0u);
         return;
     }
-    const int wq = (int)(vs >> 6) & 3, b = (int)(vs >> 4) & 3, lr = (int)vs & 15;
-    uint16_t* const base = qhat + (((((int64_t)B * 4 + wq) * 4 + b) * KS) * 64 + lr) * 8;
     float s = 0.0f;
-    if (used)
-        for (int64_t i = lane * 4; i < D; i += 256) {      // 1/||q|| with query_prep_kernel's arithmetic
-            const float4 u = *reinterpret_cast<const float4*>(x + (int64_t)q * D + i);
-            s = fmaf(u.x, u.x, s); s = fmaf(u.y, u.y, s); s = fmaf(u.z, u.z, s); s = fmaf(u.w, u.w, s);
-        }
+    for (int64_t i = lane * 4; i < D; i += 256) {          // 1/||q|| with query_prep_kernel's arithmetic
+        const float4 u = *reinterpret_cast<const float4*>(x + q * D + i);
+        s = fmaf(u.x, u.x, s); s = fmaf(u.y, u.y, s); s = fmaf(u.z, u.z, s); s = fmaf(u.w, u.w, s);
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
     const float iqv = 1.0f / fmaxf(sqrtf(s), 1e-12f);
-    if (lane == 0 && used) inv[q] = iqv;                   // (written by each of the query's 8 slots: same value)
     float e2 = 0.0f;
-    for (int c = lane; c < KS * 4; c += 64) {
+    for (int c = lane; c < KS * 4; c += 64) {              // chunk c: k = 8c .. 8c+7 = k-step c/4, k-group c%4
         f32x8v v;
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = 0.0f;
         const int64_t k0 = 8 * (int64_t)c;
-        if (used && k0 < D) {
-            const float4 u = *reinterpret_cast<const float4*>(x + (int64_t)q * D + k0);
+        if (k0 < D) {
+            const float4 u = *reinterpret_cast<const float4*>(x + q * D + k0);
             v[0] = u.x * iqv; v[1] = u.y * iqv; v[2] = u.z * iqv; v[3] = u.w * iqv;
             if (k0 + 4 < D) {
-                const float4 w = *reinterpret_cast<const float4*>(x + (int64_t)q * D + k0 + 4);
+                const float4 w = *reinterpret_cast<const float4*>(x + q * D + k0 + 4);
                 v[4] = w.x * iqv; v[5] = w.y * iqv; v[6] = w.z * iqv; v[7] = w.w * iqv;
             }
         }
         const bf16x8v bv = __builtin_convertvector(v, bf16x8v);
-        *reinterpret_cast<bf16x8v*>(base + ((int64_t)(c >> 2) * 64 + (c & 3) * 16) * 8) = bv;
+        *reinterpret_cast<bf16x8v*>(base + c * 8) = bv;
         const f32x8v back = __builtin_convertvector(bv, f32x8v);
 #pragma unroll
         for (int e = 0; e < 8; ++e) { const float d = back[e] - v[e]; e2 = fmaf(d, d, e2); }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) e2 += __shfl_xor(e2, off);
-    if (lane == 0) {                                        // query part of the error bound (coarse_prep_kernel)
-        const float eqv = used ? coarse_eq_from_e2(e2, (float)D) : 0.0f;
-        eq_slot[vs] = eqv;
-        if (used) eq_q[q] = eqv;                            // (each of the query's slots: same value)
+    if (lane == 0) {
+        inv[q] = iqv;
+        eq_q[q] = coarse_eq_from_e2(e2, (float)D);          // query part of the error bound (coarse_prep_kernel)
     }
+    if (lane < 8) qslot[q * 8 + lane] = -1;                 // probes without a slot (dropped ids) stay -1
+}
+
+// ---- per block slot (one thread each): slot <-> query maps, +inf thresholds, the slot's eq ----
+__global__ __launch_bounds__(256) void ivf2_slots_kernel(const int32_t* __restrict__ lq_cnt,
+                                                         const int32_t* __restrict__ lq_list,   // [256][IVF2_MAXQ]
+                                                         const int32_t* __restrict__ blk_off,
+                                                         const int32_t* __restrict__ blk_list,
+                                                         const int32_t* __restrict__ nblk,
+                                                         const float* __restrict__ eq_q,
+                                                         int32_t* __restrict__ slotq, int32_t* __restrict__ qslot,
+                                                         uint32_t* __restrict__ thr, float* __restrict__ eq_slot) {
+    const int64_t vs = (int64_t)blockIdx.x * 256 + threadIdx.x;            // virtual slot = B * 256 + slot
+    const int B = (int)(vs >> 8);
+    if (B >= nblk[0]) return;
+    const int list = blk_list[B];
+    const int ls = (B - blk_off[list]) * 256 + (int)(vs & 255);           // slot inside the list's query list
+    int q = -1, p = 0;
+    if (ls < ivf2_list_queries(lq_cnt, list)) {
+        const int packed = lq_list[(int64_t)list * IVF2_MAXQ + ls];
+        q = packed >> 4; p = packed & 15;
+    }
+    slotq[vs] = q;
+    thr[vs] = 0xff800000u;                                  // ord_key(+inf): nothing passes until the threshold
+    eq_slot[vs] = q >= 0 ? eq_q[q] : 0.0f;                  // kernel lowers it; padding columns stay finite
+    if (q >= 0) qslot[(int64_t)q * 8 + p] = (int32_t)vs;
+}
+
+// ---- per sorted row: the score constants (bank row id's bits in .w).  They depend on the bank and on `now`
+//      only: aura_ivf2_row_constants lets the caller keep them across calls (aura_ivf2_append updates the
+//      entries it touches), otherwise they are recomputed per call into the workspace ----
+__global__ __launch_bounds__(256) void ivf2_rowc_kernel(const float* __restrict__ meta, const float* __restrict__ rho,
+                                                        const int32_t* __restrict__ sorted_rows, int64_t Npad,
+                                                        float now, float D, float4* __restrict__ rowc) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= Npad) return;
+    rowc[i] = ivf2_row_constants(sorted_rows[i], meta, rho, now, D);
 }
 
 // ---- thresholds: one wave per query over the group maxima of its nprobe lists' sample tiles ----
@@ -239,8 +245,8 @@ __global__ __launch_bounds__(256) void ivf2_threshold_kernel(const float* __rest
 #pragma unroll
     for (int i = 0; i < PER; ++i) key[i] = 0u;
     int vs = -1;
-    if (p < nprobe) {
-        vs = qslot[(int64_t)q * 8 + p];
+    if (p < nprobe) vs = qslot[(int64_t)q * 8 + p];       // -1: the probe was dropped (id out of range / repeated)
+    if (vs >= 0) {
         const int list = blk_list[vs >> 8];
         const int tiles = (list_len[list] + 15) / 16;
         const int groups = 2 * (tiles < STL ? tiles : STL);
@@ -263,7 +269,7 @@ __global__ __launch_bounds__(256) void ivf2_threshold_kernel(const float* __rest
     // ... and a k-th largest maximum that belongs to a pad-only group (-inf) must not become the bound
     // either: "U >= -inf" would admit the padding rows, whose row id is -1
     if (T < 0x00800000u) T = 0x00800000u;                  // ord_key(-FLT_MAX): real rows pass, pads (-inf) do not
-    if (p < nprobe && (lane & 7) == 0) thr[vs] = T;
+    if (vs >= 0 && (lane & 7) == 0) thr[vs] = T;
     if (lane == 0) cnt_out[(int64_t)q * CNT_STRIDE] = 0;
 }
 
@@ -318,7 +324,7 @@ static Ivf2Workspace carve_ivf2(void* base, int64_t Npad, int64_t nq, int k) {
     w.eq_slot = reinterpret_cast<float*>(take(mb * 256 * 4));
     w.eq_q = reinterpret_cast<float*>(take(qp * 4));
     w.gmax = reinterpret_cast<float*>(take(mb * 256 * 2 * ivf2_stiles(Npad) * 4));
-    w.qhat = reinterpret_cast<uint16_t*>(take(mb * 256 * 768 * 2));
+    w.qhat = reinterpret_cast<uint16_t*>(take((qp + 1) * 768 * 2));   // one fragment set per query + the zero entry
     w.rowc = reinterpret_cast<float4*>(take((Npad > 0 ? Npad : 1) * 16));
     w.bytes = off;
     return w;

@@ -541,9 +541,10 @@ def build_ivf2(bank, inv_norm, cids, slack: int = 0, max_rows: Optional[int] = N
 
 
 def ivf2_append(bank, inv_norm, meta, slots, sorted_shadow, sorted_rows, pad_off, list_len, pos_of_row, rho,
-                flag) -> None:
+                flag, row_constants=None, row_constants_now: float = 0.0) -> None:
     """Keep the inverted lists current after a write of the DISTINCT rows ``slots`` (int64 [n]): the
-    row's old entry becomes a hole, the row is appended to the list of meta[slot][2]."""
+    row's old entry becomes a hole, the row is appended to the list of meta[slot][2].  ``row_constants``
+    (``ivf2_row_constants`` for ``row_constants_now``): the cached table follows the touched entries."""
     _need(bank, "bank", torch.float32); _need(inv_norm, "inv_norm", torch.float32)
     _need(meta, "meta", torch.float32); _need(slots, "slots", torch.int64)
     _need(sorted_shadow, "sorted_shadow", torch.bfloat16); _need(rho, "rho", torch.float32)
@@ -554,9 +555,27 @@ def ivf2_append(bank, inv_norm, meta, slots, sorted_shadow, sorted_rows, pad_off
     if sorted_shadow.shape[1] != D or sorted_shadow.shape[0] < sorted_rows.numel() or pad_off.numel() != 257 or \
             list_len.numel() != 256 or pos_of_row.numel() != M or rho.numel() != M or meta.shape != (M, 4) or D % 8:
         raise ValueError("ivf2_append: shape mismatch")
+    if row_constants is not None:
+        _need(row_constants, "row_constants", torch.float32)
+        if row_constants.dim() != 2 or row_constants.shape[1] != 4 or row_constants.shape[0] < sorted_rows.numel():
+            raise ValueError("ivf2_append: row_constants must be [>= sorted rows, 4]")
     check(lib().aura_ivf2_append(_p(bank), _p(inv_norm), _p(meta), _p(slots), slots.numel(), D, _p(sorted_shadow),
                                  _p(sorted_rows), _p(pad_off), _p(list_len), _p(pos_of_row), _p(rho), _p(flag),
-                                 _stream()), "aura_ivf2_append")
+                                 _p(row_constants), float(row_constants_now), _stream()), "aura_ivf2_append")
+
+
+def ivf2_row_constants(meta, rho, sorted_rows, n_sorted: int, D: int, now: float, out) -> None:
+    """out[i] (fp32 [>= n_sorted, 4]) = the score constants of sorted row i at time ``now`` (see
+    ``aura_ivf2_row_constants``): pass ``out`` to ``knn_search_ivf2(row_constants=...)`` for calls with the
+    same ``now`` while metadata, rho and the list layout are unchanged."""
+    _need(meta, "meta", torch.float32); _need(rho, "rho", torch.float32)
+    _need(sorted_rows, "sorted_rows", torch.int32); _need(out, "out", torch.float32)
+    n = int(n_sorted)
+    if out.dim() != 2 or out.shape[1] != 4 or not (0 <= n <= min(out.shape[0], sorted_rows.numel())) or \
+            meta.dim() != 2 or meta.shape[1] != 4 or rho.numel() != meta.shape[0]:
+        raise ValueError("ivf2_row_constants: shape mismatch")
+    check(lib().aura_ivf2_row_constants(_p(meta), _p(rho), _p(sorted_rows), n, int(D), float(now), _p(out), _stream()),
+          "aura_ivf2_row_constants")
 
 
 def centroid_probe(queries, centroids, nprobe: int = 8) -> torch.Tensor:
@@ -581,14 +600,15 @@ def centroid_probe(queries, centroids, nprobe: int = 8) -> torch.Tensor:
 
 def knn_search_ivf2(bank, inv_norm, meta, queries, k: int, now: float, centroids, nprobe: int,
                     sorted_shadow, rho, sorted_rows, pad_off, list_len, idx_base: int = 0,
-                    n_sorted: Optional[int] = None, lists_flag=None, probe_ids=None
+                    n_sorted: Optional[int] = None, lists_flag=None, probe_ids=None, row_constants=None
                     ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """Inverted-list recall through the two-stage scan: (scores [nq, k], idx [nq, k], overflow flag [1]).
     Same results as ``knn_search_ivf``; layout arrays from ``ivf2_layout`` + ``bank_shadow_sorted``
     (kept current by ``ivf2_append``).  ``n_sorted``: sorted rows in use (a multiple of 16 that covers
     pad_off[256]; default: all of ``sorted_rows``).  ``lists_flag``: ``ivf2_append``'s flag; if it is
     set the returned overflow flag carries ``KNN_FLAG_LISTS_STALE``.  ``probe_ids``: ``centroid_probe``'s
-    output for these queries and this centroid table (the probes are then not recomputed)."""
+    output for these queries and this centroid table (the probes are then not recomputed).
+    ``row_constants``: ``ivf2_row_constants`` of the current lists for exactly this ``now`` (as fp32)."""
     _need(bank, "bank", torch.float32); _need(inv_norm, "inv_norm", torch.float32)
     _need(meta, "meta", torch.float32); _need(queries, "queries", torch.float32)
     _need(centroids, "centroids", torch.float32); _need(sorted_shadow, "sorted_shadow", torch.bfloat16)
@@ -619,18 +639,24 @@ def knn_search_ivf2(bank, inv_norm, meta, queries, k: int, now: float, centroids
     base = (ws.data_ptr() + 255) // 256 * 256
     if lists_flag is not None:
         _need(lists_flag, "lists_flag", torch.int32)
+    if row_constants is not None:
+        _need(row_constants, "row_constants", torch.float32)
+        if row_constants.dim() != 2 or row_constants.shape[1] != 4 or row_constants.shape[0] < ns:
+            raise ValueError("knn_search_ivf2: row_constants must be [>= n_sorted, 4]")
     if probe_ids is not None:
         _need(probe_ids, "probe_ids", torch.int32)
         if tuple(probe_ids.shape) != (nq, 8):
             raise ValueError("knn_search_ivf2: probe_ids must be [nq, 8] (centroid_probe)")
         check(L.aura_knn_search_ivf2_probed(_p(bank), _p(inv_norm), _p(meta), _p(sorted_shadow), _p(rho),
-                                            _p(sorted_rows), _p(pad_off), _p(list_len), _p(lists_flag), ns, M,
+                                            _p(sorted_rows), _p(pad_off), _p(list_len), _p(lists_flag),
+                                            _p(row_constants), ns, M,
                                             _p(queries), now, D, nq, k, _p(centroids), nprobe, _p(probe_ids),
                                             idx_base, _p(out_s), _p(out_i), base, nbytes, _p(ovf), _stream()),
               "aura_knn_search_ivf2_probed")
         return out_s, out_i, ovf
     check(L.aura_knn_search_ivf2(_p(bank), _p(inv_norm), _p(meta), _p(sorted_shadow), _p(rho), _p(sorted_rows),
-                                 _p(pad_off), _p(list_len), _p(lists_flag), ns, M, _p(queries), now, D, nq, k,
+                                 _p(pad_off), _p(list_len), _p(lists_flag), _p(row_constants), ns, M, _p(queries), now, D,
+                                 nq, k,
                                  _p(centroids), nprobe, idx_base, _p(out_s), _p(out_i), base, nbytes,
                                  _p(ovf), _stream()), "aura_knn_search_ivf2")
     return out_s, out_i, ovf

@@ -267,7 +267,17 @@ int aura_knn_search_shadow(const float* bank, const uint16_t* bank_bf16, const f
  * what aura_knn_search_ivf2 computes for itself; workspace: aura_centroid_probe_workspace_bytes(nq)
  * bytes, 256-byte aligned.  aura_knn_search_ivf2_probed takes such ids (of the same queries and
  * centroid table) instead of recomputing them: a bank sharded over ranks that share one centroid table
- * probes every query once, on the rank that owns it, not once per rank. */
+ * probes every query once, on the rank that owns it, not once per rank.
+ * row_constants (optional, [n_sorted][4] fp32, 16-byte aligned): the sorted rows' score constants
+ * {0.5 strength, temporal term + error, temporal term - error, bank row id bits} -- the per-row half of
+ * hippocampal.py:290-303's combined score as the prefilter bounds it.  They depend on the bank's metadata,
+ * rho, the list layout and `now` only, so a caller may build them once with aura_ivf2_row_constants(now)
+ * and pass them to every search that uses the SAME `now` (fp32: the reference's fp32 timestamps give it a
+ * 128-second grain) until metadata or layout change; aura_ivf2_append keeps a table current for the
+ * entries it touches (pass the table and its `now`; NULL: no table).  NULL in the search: computed per
+ * call into the workspace. */
+int aura_ivf2_row_constants(const float* meta, const float* rho, const int32_t* sorted_rows, int64_t n_sorted,
+                            int64_t D, float now, float* row_constants, void* stream);
 int64_t aura_knn_ivf2_workspace_bytes(int64_t n_sorted, int64_t nq, int k);
 int64_t aura_centroid_probe_workspace_bytes(int64_t nq);
 int aura_centroid_probe(const float* centroids, const float* queries, int64_t D, int64_t nq, int nprobe,
@@ -277,10 +287,12 @@ int aura_bank_shadow_sorted(const float* bank, const float* inv_norm, const int3
                             void* stream);
 int aura_ivf2_append(const float* bank, const float* inv_norm, const float* meta, const int64_t* slots,
                      int64_t n, int64_t D, uint16_t* sorted_bf16, int32_t* sorted_rows, const int32_t* pad_off,
-                     int32_t* list_len, int32_t* pos_of_row, float* rho, int32_t* flag, void* stream);
+                     int32_t* list_len, int32_t* pos_of_row, float* rho, int32_t* flag, float* row_constants,
+                     float row_constants_now, void* stream);
 int aura_knn_search_ivf2(const float* bank, const float* inv_norm, const float* meta,
                          const uint16_t* sorted_bf16, const float* rho, const int32_t* sorted_rows,
                          const int32_t* pad_off, const int32_t* list_len, const int32_t* lists_flag,
+                         const float* row_constants,
                          int64_t n_sorted, int64_t N, const float* queries, float now, int64_t D, int64_t nq, int k,
                          const float* centroids, int nprobe, int32_t idx_base, float* out_scores,
                          int32_t* out_idx, void* workspace, int64_t workspace_bytes, int32_t* overflow_out,
@@ -288,6 +300,7 @@ int aura_knn_search_ivf2(const float* bank, const float* inv_norm, const float* 
 int aura_knn_search_ivf2_probed(const float* bank, const float* inv_norm, const float* meta,
                                 const uint16_t* sorted_bf16, const float* rho, const int32_t* sorted_rows,
                                 const int32_t* pad_off, const int32_t* list_len, const int32_t* lists_flag,
+                                const float* row_constants,
                                 int64_t n_sorted, int64_t N, const float* queries, float now, int64_t D, int64_t nq,
                                 int k, const float* centroids, int nprobe, const int32_t* probe_ids, int32_t idx_base,
                                 float* out_scores, int32_t* out_idx, void* workspace, int64_t workspace_bytes,
