@@ -39,6 +39,8 @@ SIGNATURES = {
     "aura_gif_run": (I, [P, P, P, P, F, I, F, F, I64, I64, I64, I, I, P]),
     "aura_bank_row_norms": (I, [P, P, I64, I64, I64, P]),
     "aura_bank_write": (I, [P, P, P, P, P, P, I, P, P, P, I, F, I64, I64, P]),
+    "aura_bank_write_online_workspace_bytes": (I64, [I64]),
+    "aura_bank_write_online": (I, [P, P, P, P, P, P, I, P, P, P, I, F, I64, I64, P, I64, P]),
     "aura_bank_decay": (I, [P, F, I64, P]),
     "aura_knn_workspace_bytes": (I64, [I64, I64, I]),
     "aura_knn_search": (I, [P, P, P, P, I, P, P, F, I64, I64, I64, I, I32, P, P, P, I64, P]),

@@ -471,7 +471,7 @@ class HippocampalFormation(nn.Module):
                        now,
                        centroids=self.centroids if online else None,
                        centroid_counts=self.centroid_counts if online else None,
-                       eff_k=eff_k if online else 0)
+                       eff_k=eff_k if online else 0, distinct_slots=keep is None)
         if cids is not None:
             c = cids.to(device=self.device, dtype=torch.float32)
             self.memory_metadata[uniq_t, 2] = c if keep is None else c[keep_t]

@@ -243,6 +243,205 @@ __global__ __launch_bounds__(1024) void bank_write_centroid_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// The same online update with the distances taken out of the serial chain (round 3).  The serial kernel
+// above stays as the checker (and serves batches that name a slot twice); results are bit-identical:
+//   phase 0  bank_write_kernel: rows, norms, locations, metadata shells -- parallel, as without the index;
+//   phase A  online_dist0_kernel: d0[i][c] = distance of row i to centroid c AS THE TABLE STANDS AT BATCH
+//            START, with exactly the serial kernel's arithmetic (per-lane fmaf chain, butterfly, sqrtf);
+//   phase B  online_assign_kernel: ONE workgroup walks the rows in order.  Centroid c has moved, since
+//            batch start, by at most delta[c] = sum of ||step|| over the rows assigned to it so far (a step
+//            is eta (x - c): its length is eta times a distance the pass already holds), so the distance
+//            the serial kernel would compute now lies in d0 +- (delta[c] + fp slack); for a centroid that
+//            has not moved it IS d0, bit for bit.  Row i's candidates are the centroids whose lower bound
+//            does not exceed the smallest upper bound: usually one -- the answer, no distance computed --
+//            otherwise the candidates (typically 2-4 of 256) are re-scored against the current table with
+//            the serial arithmetic and the first minimum wins, as torch.argmin.  Then counts, eta, the
+//            running mean (same expression as above), delta.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float centroid_dist_wave(const float* __restrict__ x, const float* __restrict__ c,
+                                                    int64_t D, int lane, bool vec4) {
+    float acc = 0.0f;
+    if (vec4) {
+        for (int64_t j = lane * 4; j < D; j += 256) {
+            const float4 xv = *reinterpret_cast<const float4*>(x + j);
+            const float4 cv = *reinterpret_cast<const float4*>(c + j);
+            float d = cv.x - xv.x; acc = fmaf(d, d, acc);
+            d = cv.y - xv.y; acc = fmaf(d, d, acc);
+            d = cv.z - xv.z; acc = fmaf(d, d, acc);
+            d = cv.w - xv.w; acc = fmaf(d, d, acc);
+        }
+    } else {
+        for (int64_t j = lane; j < D; j += 64) {
+            const float d = c[j] - x[j];
+            acc = fmaf(d, d, acc);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    return sqrtf(acc);
+}
+
+constexpr int ONL_CG = 8;                   // centroids per wave task of phase A
+constexpr int ONL_CHUNK = 4096;             // rows per phase A / phase B pair (workspace: 257 floats per row)
+
+__global__ __launch_bounds__(256) void online_dist0_kernel(const float* __restrict__ feats,
+                                                           const float* __restrict__ centroids, int eff_k,
+                                                           int64_t n, int64_t D, int vec4,
+                                                           float* __restrict__ d0,       // [n][256]
+                                                           float* __restrict__ xnorm) {  // [n] upper bound of ||x_i||
+    const int lane = threadIdx.x & 63;
+    const int groups = (eff_k + ONL_CG - 1) / ONL_CG;
+    const int64_t task = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (task >= n * groups) return;
+    const int64_t i = task / groups;
+    const int g = (int)(task - i * groups);
+    const float* const x = feats + i * D;
+#pragma unroll 2
+    for (int u = 0; u < ONL_CG; ++u) {
+        const int c = g * ONL_CG + u;
+        if (c >= eff_k) break;
+        const float d = centroid_dist_wave(x, centroids + (int64_t)c * D, D, lane, vec4 != 0);
+        if (lane == 0) d0[i * 256 + c] = d;
+    }
+    if (g == 0) {
+        const float s = wave_row_sumsq(x, D, lane, vec4 != 0);
+        if (lane == 0) xnorm[i] = sqrtf(s) * 1.0001f;
+    }
+}
+
+__global__ __launch_bounds__(1024) void online_assign_kernel(float* meta, float* centroids, float* counts, int eff_k,
+                                                             const float* __restrict__ feats,
+                                                             const int64_t* __restrict__ slots,
+                                                             const float* __restrict__ d0,
+                                                             const float* __restrict__ xnorm, int64_t n, int64_t D,
+                                                             int vec4, float rel) {
+    extern __shared__ __attribute__((aligned(16))) float s_row[];   // [D] (re-scoring only)
+    __shared__ float s_delta[256], s_counts[256], s_fresh[256];
+    __shared__ int s_cand[256];
+    __shared__ int s_ncand, s_best;
+    __shared__ float s_dwin;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 256) {
+        s_delta[tid] = 0.0f;
+        s_counts[tid] = tid < eff_k ? counts[tid] : 0.0f;
+    }
+    __syncthreads();
+    // what wave 0 does once row i's centroid is known: count, step bound, metadata
+    auto commit = [&](int64_t i, int best, float dwin_up) {   // (one lane)
+        const float cn = s_counts[best] + 1.0f;
+        s_counts[best] = cn;
+        const float eta = 1.0f / fmaxf(cn, 1.0f);
+        // ||step|| <= eta ||x - c|| + rounding of the mean's three roundings per coordinate:
+        // <= 4 u (||c|| + eta ||x||), ||c|| <= ||x|| + ||x - c||
+        s_delta[best] += 1.0001f * (eta * dwin_up) + 3e-7f * (2.0f * xnorm[i] + dwin_up);
+        meta[slots[i] * 4 + 2] = (float)best;
+        s_best = best;
+    };
+    for (int64_t i = 0; i < n; ++i) {
+        if (wave == 0) {
+            float lo[4], hi[4], dv[4], dl[4];
+            float hmin = INFINITY;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = lane + 64 * u;
+                const bool valid = c < eff_k;
+                dv[u] = valid ? d0[i * 256 + c] : INFINITY;
+                dl[u] = s_delta[c];
+                const float m = dl[u] == 0.0f ? 0.0f : dv[u] * rel + dl[u] * 1.0001f;   // unmoved: d0 is the value itself
+                lo[u] = valid ? dv[u] - m : INFINITY;
+                hi[u] = valid ? dv[u] + m : INFINITY;
+                hmin = fminf(hmin, hi[u]);                   // (NaN distances never become candidates, as in the
+            }                                                //  serial kernel's `d < best` scan)
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) hmin = fminf(hmin, __shfl_xor(hmin, off));
+            unsigned long long cm[4];
+            int total = 0;
+            bool moved = false;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool cnd = lo[u] <= hmin;
+                cm[u] = __ballot(cnd);
+                total += (int)__popcll(cm[u]);
+                moved = moved || (cnd && dl[u] != 0.0f);
+            }
+            const bool any_moved = __ballot(moved) != 0ull;
+            if (total == 0) {                               // every distance NaN: the serial kernel answers 0
+                if (lane == 0) { s_ncand = 1; commit(i, 0, 0.0f); }
+            } else if (total == 1) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (lo[u] <= hmin) { s_ncand = 1; commit(i, lane + 64 * u, hi[u]); }
+            } else if (!any_moved) {
+                // exact ties among centroids that have not moved: their distances are d0 itself -> first minimum
+                float bd = INFINITY;
+                int best = 0x7fffffff;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (lo[u] <= hmin && dv[u] < bd) { bd = dv[u]; best = lane + 64 * u; }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const float od = __shfl_xor(bd, off);
+                    const int ob = __shfl_xor(best, off);
+                    if (od < bd || (od == bd && ob < best)) { bd = od; best = ob; }
+                }
+                if (lane == 0) { s_ncand = 1; commit(i, best, bd); }
+            } else {
+                // candidate list in ascending centroid order (c = 64 u + lane)
+                int base = 0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (lo[u] <= hmin) {
+                        const int p = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(cm[u] >> 32),
+                                                  __builtin_amdgcn_mbcnt_lo((unsigned)cm[u], 0u));
+                        s_cand[p] = lane + 64 * u;
+                    }
+                    base += (int)__popcll(cm[u]);
+                }
+                if (lane == 0) s_ncand = total;
+            }
+        }
+        __syncthreads();
+        const int ncand = s_ncand;
+        if (ncand > 1) {                                    // (workgroup-uniform)
+            for (int64_t j = tid; j < D; j += 1024) s_row[j] = feats[i * D + j];
+            __threadfence_block();                          // earlier rows' centroid stores are visible to every wave
+            __syncthreads();
+            for (int ci = wave; ci < ncand; ci += 16) {
+                const float d = centroid_dist_wave(s_row, centroids + (int64_t)s_cand[ci] * D, D, lane, vec4 != 0);
+                if (lane == 0) s_fresh[ci] = d;
+            }
+            __syncthreads();
+            if (wave == 0) {                                // first minimum; the list is in ascending centroid order
+                float bd = INFINITY;
+                int bi = 0x7fffffff;
+                for (int ci = lane; ci < ncand; ci += 64) {
+                    const float d = s_fresh[ci];
+                    if (d < bd) { bd = d; bi = ci; }
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const float od = __shfl_xor(bd, off);
+                    const int ob = __shfl_xor(bi, off);
+                    if (od < bd || (od == bd && ob < bi)) { bd = od; bi = ob; }
+                }
+                // (all re-scored distances NaN cannot be: a candidate had a finite bound)
+                if (lane == 0) commit(i, s_cand[bi == 0x7fffffff ? 0 : bi], bd * (1.0f + rel));
+            }
+            __syncthreads();
+        }
+        const int best = s_best;
+        const float eta = 1.0f / fmaxf(s_counts[best], 1.0f);
+        const float one_m = 1.0f - eta;
+        float* cp = centroids + (int64_t)best * D;
+        const float* xr = feats + i * D;
+        for (int64_t j = tid; j < D; j += 1024) cp[j] = one_m * cp[j] + eta * xr[j];
+        __threadfence_block();                              // the store is done before this thread touches the row again
+        __syncthreads();                                    // s_best / s_ncand / s_counts are rewritten next
+    }
+    if (tid < eff_k) counts[tid] = s_counts[tid];
+}
+
 __global__ __launch_bounds__(256) void bank_decay_kernel(float* meta, float factor, int64_t count) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < count) meta[i * 4] *= factor;
@@ -850,7 +1049,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void knn_scan_filter_v2(const ScanArg
 // ranking key is ||c||^2 - 2 q.c: the query's own norm -- 768 for a Gaussian query, where the key is O(10)
 // -- never enters, which makes the key MORE accurate in fp32 than the direct sum of 768 squares.  q.c runs
 // on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulation).
-//   workgroup = 16 queries x 256 centroids, 4 waves; wave w owns centroids [64 w, 64 w + 64) as four
+//   workgroup = 16 queries x 256 centroids, 8 waves; wave w owns centroids [32 w, 32 w + 32) as two
 //   16 x 16 output tiles.  Lane (r = lane & 15, h = lane >> 4) loads 16 bytes of query row r and of
 //   centroid rows 16 t + r at k = 16 j + 4 h: element m of those loads is the lane's A / B value of the
 //   j-th group's m-th MFMA (any k permutation is fine as long as A and B use the same one).  ||c||^2
@@ -862,10 +1061,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void knn_scan_filter_v2(const ScanArg
 //   list is whatever the atomics make it (results do not depend on it).
 // ------------------------------------------------------------------------------------------
 constexpr int PR_Q = 16;                   // queries per workgroup
+constexpr int PR_WAVES = 8;                // waves per workgroup: wave w owns centroids [32 w, 32 w + 32)
+constexpr int PR_T = 256 / PR_WAVES / 16;  // 16 x 16 output tiles per wave
+constexpr int PR_G = 4;                    // k-groups (16 k each) per software-pipeline stage
 constexpr int PR_KSTRIDE = 260;            // floats per key row in LDS (260 % 32 = 4: the four query groups of a
                                            // wave read different banks)
 
-__global__ __launch_bounds__(256) void centroid_probe_kernel(const float* __restrict__ centroids,
+__global__ __launch_bounds__(64 * PR_WAVES) void centroid_probe_kernel(const float* __restrict__ centroids,
                                                              const float* __restrict__ queries,
                                                              int64_t D, int nq, int nprobe,
                                                              uint32_t* __restrict__ mask_out,
@@ -876,13 +1078,13 @@ __global__ __launch_bounds__(256) void centroid_probe_kernel(const float* __rest
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, h = lane >> 4;
     const int q0 = blockIdx.x * PR_Q;
-    const int c0 = wave * 64;
+    const int c0 = wave * (16 * PR_T);
     const bool vec = (D & 3) == 0 && ((reinterpret_cast<uintptr_t>(queries) | reinterpret_cast<uintptr_t>(centroids)) & 15) == 0;
     const int qrow = q0 + r < nq ? q0 + r : nq - 1;          // rows beyond nq repeat the last query (never written)
     const float* const qp = queries + (int64_t)qrow * D;
-    const float* cp[4];
+    const float* cp[PR_T];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) cp[t] = centroids + (int64_t)(c0 + 16 * t + r) * D;
+    for (int t = 0; t < PR_T; ++t) cp[t] = centroids + (int64_t)(c0 + 16 * t + r) * D;
     auto ld = [&](const float* base, int64_t k) -> float4 {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (vec) { if (k < D) v = *reinterpret_cast<const float4*>(base + k); }
@@ -894,51 +1096,70 @@ __global__ __launch_bounds__(256) void centroid_probe_kernel(const float* __rest
         }
         return v;
     };
-    f32x4v_t acc[4];
-    float cn[4];
+    f32x4v_t acc[PR_T];
+    float cn[PR_T];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) { acc[t] = f32x4v_t{0.f, 0.f, 0.f, 0.f}; cn[t] = 0.0f; }
-    float4 a = ld(qp, 4 * h), b[4];
+    for (int t = 0; t < PR_T; ++t) { acc[t] = f32x4v_t{0.f, 0.f, 0.f, 0.f}; cn[t] = 0.0f; }
+    // one stage = PR_G k-groups: (1 + PR_T) PR_G 16-byte loads per lane in flight while the previous stage's
+    // 4 PR_T PR_G MFMAs run; two waves per SIMD cover the rest of the L2 latency (the first version kept one
+    // k-group in flight with one wave per SIMD: 103 us per 2048 queries, all of it load latency)
+    float4 a[PR_G], b[PR_G][PR_T];
+    auto load_stage = [&](float4 (&aa)[PR_G], float4 (&bb)[PR_G][PR_T], int64_t k0) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) b[t] = ld(cp[t], 4 * h);
-    for (int64_t k0 = 0; k0 < D; k0 += 16) {
-        float4 an = make_float4(0.f, 0.f, 0.f, 0.f), bn[4];
+        for (int g = 0; g < PR_G; ++g) {
+            aa[g] = ld(qp, k0 + 16 * g + 4 * h);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) bn[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k0 + 16 < D) {                                   // next group's loads fly during the 16 MFMAs
-            an = ld(qp, k0 + 16 + 4 * h);
+            for (int t = 0; t < PR_T; ++t) bb[g][t] = ld(cp[t], k0 + 16 * g + 4 * h);
+        }
+    };
+    load_stage(a, b, 0);
+    for (int64_t k0 = 0; k0 < D; k0 += 16 * PR_G) {
+        float4 an[PR_G], bn[PR_G][PR_T];
+        if (k0 + 16 * PR_G < D) load_stage(an, bn, k0 + 16 * PR_G);
+        else {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) bn[t] = ld(cp[t], k0 + 16 + 4 * h);
+            for (int g = 0; g < PR_G; ++g) {
+                an[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int t = 0; t < PR_T; ++t) bn[g][t] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            cn[t] = fmaf(b[t].x, b[t].x, cn[t]); cn[t] = fmaf(b[t].y, b[t].y, cn[t]);
-            cn[t] = fmaf(b[t].z, b[t].z, cn[t]); cn[t] = fmaf(b[t].w, b[t].w, cn[t]);
+        for (int g = 0; g < PR_G; ++g) {
+#pragma unroll
+            for (int t = 0; t < PR_T; ++t) {
+                cn[t] = fmaf(b[g][t].x, b[g][t].x, cn[t]); cn[t] = fmaf(b[g][t].y, b[g][t].y, cn[t]);
+                cn[t] = fmaf(b[g][t].z, b[g][t].z, cn[t]); cn[t] = fmaf(b[g][t].w, b[g][t].w, cn[t]);
+            }
+#pragma unroll
+            for (int t = 0; t < PR_T; ++t) {
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g].x, b[g][t].x, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g].y, b[g][t].y, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g].z, b[g][t].z, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g].w, b[g][t].w, acc[t], 0, 0, 0);
+            }
         }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[t].x, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[t].y, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[t].z, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[t].w, acc[t], 0, 0, 0);
-        }
-        a = an;
+        for (int g = 0; g < PR_G; ++g) {
+            a[g] = an[g];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) b[t] = bn[t];
+            for (int t = 0; t < PR_T; ++t) b[g][t] = bn[g][t];
+        }
     }
     // ||c||^2 of centroid c0 + 16 t + r: the four h lanes hold its partials
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < PR_T; ++t) {
         cn[t] += __shfl_xor(cn[t], 16);
         cn[t] += __shfl_xor(cn[t], 32);
     }
     // C/D layout: lane -> centroid column r, query rows 4 h + e
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < PR_T; ++t)
 #pragma unroll
         for (int e = 0; e < 4; ++e)
             s_key[(4 * h + e) * PR_KSTRIDE + c0 + 16 * t + r] = fmaf(-2.0f, acc[t][e], cn[t]);
     __syncthreads();
+    if (wave >= PR_Q / 4) return;
 
     // ---- selection: 16 lanes per query (query 4 wave + h of the workgroup), lane r holds centroids r + 16 m ----
     const int ql = 4 * wave + h;
@@ -987,7 +1208,7 @@ inline int launch_probe(const float* centroids, const float* queries, int64_t D,
                         int32_t* lq_cnt = nullptr, int32_t* lq_list = nullptr, int lq_stride = 0) {
     (void)dist_ws;
     if (nq <= 0) return AURA_OK;
-    hipLaunchKernelGGL(centroid_probe_kernel, dim3((unsigned)((nq + PR_Q - 1) / PR_Q)), dim3(256), 0, s,
+    hipLaunchKernelGGL(centroid_probe_kernel, dim3((unsigned)((nq + PR_Q - 1) / PR_Q)), dim3(64 * PR_WAVES), 0, s,
                        centroids, queries, D, nq, nprobe, mask_out, ids_out, lq_cnt, lq_list, lq_stride);
     return hipGetLastError() == hipSuccess ? AURA_OK : AURA_E_LAUNCH;
 }
@@ -1911,6 +2132,53 @@ int aura_bank_write(float* bank, float* loc, float* meta, float* inv_norm, float
                            loc, meta, inv_norm, feats, slots, cur_loc, spatial_dims, now, -1.0f, n, D, vec4);
     }
     return check_launch();
+}
+
+int64_t aura_bank_write_online_workspace_bytes(int64_t n) {
+    if (n < 0) return -1;
+    const int64_t ch = n < ONL_CHUNK ? (n > 0 ? n : 1) : ONL_CHUNK;
+    return align_up(ch * 256 * 4, 256) + align_up(ch * 4, 256);
+}
+
+int aura_bank_write_online(float* bank, float* loc, float* meta, float* inv_norm, float* centroids,
+                           float* centroid_counts, int eff_k, const float* feats, const int64_t* slots,
+                           const float* cur_loc, int spatial_dims, float now, int64_t n, int64_t D,
+                           void* workspace, int64_t workspace_bytes, void* stream) {
+    if (n < 0 || D <= 0 || spatial_dims < 0 || spatial_dims > 64) return AURA_E_INVAL;
+    if (n == 0) return AURA_OK;
+    if (!bank || !loc || !meta || !inv_norm || !feats || !slots || !cur_loc || !centroids || !centroid_counts || !workspace)
+        return AURA_E_INVAL;
+    if (eff_k <= 0 || eff_k > 256) return AURA_E_INVAL;
+    if ((reinterpret_cast<uintptr_t>(meta) & 15) || (reinterpret_cast<uintptr_t>(workspace) & 255)) return AURA_E_ALIGN;
+    if (workspace_bytes < aura_bank_write_online_workspace_bytes(n)) return AURA_E_INVAL;
+    const size_t lds = (size_t)D * sizeof(float);
+    if (lds > 140 * 1024) return AURA_E_INVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int vec4 = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(feats) & 15) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(bank) & 15) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(centroids) & 15) == 0);
+    if (ensure_lds_attr(reinterpret_cast<const void*>(online_assign_kernel), 140 * 1024)) return AURA_E_LAUNCH;
+    hipLaunchKernelGGL(bank_write_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, bank, loc, meta, inv_norm,
+                       feats, slots, cur_loc, spatial_dims, now, -1.0f, n, D, vec4);
+    int rc;
+    if ((rc = check_launch())) return rc;
+    const int64_t ch = n < ONL_CHUNK ? n : ONL_CHUNK;
+    float* const d0 = static_cast<float*>(workspace);
+    float* const xnorm = reinterpret_cast<float*>(static_cast<char*>(workspace) + align_up(ch * 256 * 4, 256));
+    // fp slack of a computed distance against the exact one, both ways: 2 x (chain of D/64 fmaf + 6 butterfly
+    // adds + subtraction, square root) x 2^-24, with a factor 2 in hand
+    const float rel = 4.0f * ((float)((D + 63) / 64) + 10.0f) * 5.9604645e-8f;
+    const int groups = (eff_k + ONL_CG - 1) / ONL_CG;
+    for (int64_t r0 = 0; r0 < n; r0 += ch) {
+        const int64_t nr = (n - r0) < ch ? (n - r0) : ch;
+        hipLaunchKernelGGL(online_dist0_kernel, dim3((unsigned)((nr * groups + 3) / 4)), dim3(256), 0, s,
+                           feats + r0 * D, centroids, eff_k, nr, D, vec4, d0, xnorm);
+        if ((rc = check_launch())) return rc;
+        hipLaunchKernelGGL(online_assign_kernel, dim3(1), dim3(1024), lds, s, meta, centroids, centroid_counts, eff_k,
+                           feats + r0 * D, slots + r0, d0, xnorm, nr, D, vec4, rel);
+        if ((rc = check_launch())) return rc;
+    }
+    return AURA_OK;
 }
 
 int aura_bank_decay(float* meta, float rate, int64_t count, void* stream) {

@@ -286,8 +286,12 @@ def make_shadow(bank, inv_norm, count: Optional[int] = None) -> Tuple[torch.Tens
 
 
 def bank_write(bank, loc, meta, inv_norm, feats, slots, cur_loc, now: float,
-               centroids=None, centroid_counts=None, eff_k: int = 0) -> None:
-    """Write feats[n, D] into rows ``slots`` (int64 [n], device)."""
+               centroids=None, centroid_counts=None, eff_k: int = 0, distinct_slots: bool = False,
+               serial: bool = False) -> None:
+    """Write feats[n, D] into rows ``slots`` (int64 [n], device).  With ``centroids`` the reference's online
+    nearest-centroid / running-mean update runs in row order (``hippocampal.py:218-230``): through
+    ``aura_bank_write_online`` (distances out of the serial chain, same bits) when the caller vouches that the
+    slots are distinct, else -- or with ``serial`` (tests: the checker) -- through the one-workgroup kernel."""
     for t, n_ in ((bank, "bank"), (loc, "loc"), (meta, "meta"), (inv_norm, "inv_norm"),
                   (feats, "feats"), (cur_loc, "cur_loc")):
         _need(t, n_, torch.float32)
@@ -305,6 +309,15 @@ def bank_write(bank, loc, meta, inv_norm, feats, slots, cur_loc, now: float,
         if centroids.shape[1] != D or not (0 < eff_k <= centroids.shape[0] <= 256) or \
                 centroid_counts.numel() < eff_k:
             raise ValueError("bank_write: centroid shape mismatch")
+    if centroids is not None and distinct_slots and not serial and n > 0:
+        L = lib()
+        nbytes = L.aura_bank_write_online_workspace_bytes(n)
+        ws = _workspace(bank.device, nbytes)
+        base = (ws.data_ptr() + 255) // 256 * 256
+        check(L.aura_bank_write_online(_p(bank), _p(loc), _p(meta), _p(inv_norm), _p(centroids),
+                                       _p(centroid_counts), eff_k, _p(feats), _p(slots), _p(cur_loc), sd,
+                                       now, n, D, base, nbytes, _stream()), "aura_bank_write_online")
+        return
     check(lib().aura_bank_write(_p(bank), _p(loc), _p(meta), _p(inv_norm), _p(centroids),
                                 _p(centroid_counts), eff_k, _p(feats), _p(slots), _p(cur_loc), sd,
                                 now, n, D, _stream()), "aura_bank_write")

@@ -104,6 +104,18 @@ int aura_bank_write(float* bank, float* loc, float* meta, float* inv_norm, float
                     const float* cur_loc, int spatial_dims, float now, int64_t n, int64_t D,
                     void* stream);
 
+/* aura_bank_write with centroids != NULL for batches whose slots are all DISTINCT, same results bit for
+ * bit: the distances leave the serial chain -- every row is scored against the table as it stands at
+ * batch start in parallel, then one workgroup walks the rows in order and re-scores (with the serial
+ * arithmetic) only the centroids that earlier rows of the batch moved close enough to matter
+ * (hippocampal.py:218-230 is order dependent: row i sees the centroids left by rows < i).
+ * workspace: aura_bank_write_online_workspace_bytes(n) bytes, 256-byte aligned. */
+int64_t aura_bank_write_online_workspace_bytes(int64_t n);
+int aura_bank_write_online(float* bank, float* loc, float* meta, float* inv_norm, float* centroids,
+                           float* centroid_counts, int eff_k, const float* feats, const int64_t* slots,
+                           const float* cur_loc, int spatial_dims, float now, int64_t n, int64_t D,
+                           void* workspace, int64_t workspace_bytes, void* stream);
+
 /* meta[i][0] *= (1 - rate) for i < count.  Replaces decay_memories, hippocampal.py:334. */
 int aura_bank_decay(float* meta, float rate, int64_t count, void* stream);
 

@@ -21,7 +21,7 @@ def bank_row_norms(bank, inv_norm, row0, n):
 
 
 def bank_write(bank, loc, meta, inv_norm, feats, slots, cur_loc, now, centroids=None,
-               centroid_counts=None, eff_k=0):
+               centroid_counts=None, eff_k=0, distinct_slots=False, serial=False):
     for i, slot in enumerate(slots.tolist()):
         f = feats[i]
         bank[slot] = f
