@@ -75,6 +75,8 @@ SIGNATURES = {
     "aura_centroid_probe": (I, [P, P, I64, I64, I, P, P, I64, P]),
     "aura_knn_search_ivf2_probed": (I, [P, P, P, P, P, P, P, P, P, P, I64, I64, P, F, I64, I64, I, P, I, P, I32, P, P, P,
                                         I64, P, P]),
+    "aura_knn_search_ivf2_staged": (I, [P, P, P, P, P, P, P, P, P, P, I64, I64, P, F, I64, I64, I, P, I, P, I32, P, P, P,
+                                        I64, P, I, I, P, P]),
     "aura_profile_begin": (I, [I]),
     "aura_profile_end": (I, [P, I]),
     "aura_profile_last_scan": (I, [P, P]),

@@ -560,7 +560,8 @@ class HippocampalFormation(nn.Module):
                      locations: Optional[torch.Tensor] = None, now: Optional[float] = None,
                      use_candidates: Optional[bool] = None, check_overflow: bool = True,
                      fallback_empty: bool = True,
-                     probe_ids: Optional[torch.Tensor] = None, _retry: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
+                     probe_ids: Optional[torch.Tensor] = None, _retry: int = 0,
+                     bound_exchange=None) -> Tuple[torch.Tensor, torch.Tensor]:
         """Batched recall: ``(scores [nq, k'], rows [nq, k'])`` with ``k' = min(k, count)``;
         rows are bank row indices (int32), ``-1`` where a query has fewer than ``k'`` candidates.
 
@@ -572,9 +573,21 @@ class HippocampalFormation(nn.Module):
         leaves such queries at ``-1`` (a shard of a row-sharded bank: the query may have candidates
         on another shard, so the fallback is the caller's decision after the merge).  ``probe_ids``:
         ``probe(queries)`` computed earlier for these queries against the current centroid table (the
-        inverted-list path then skips its own probe; other paths ignore it)."""
+        inverted-list path then skips its own probe; other paths ignore it).  ``bound_exchange``
+        (``sharded.ShardedHippocampus``): ``(fn, parts)`` -- the inverted-list recall runs in two stages per pass of
+        at most 8192 queries and ``fn(bounds [n, 2]) -> bound [n]`` combines every shard's sampled bounds in
+        between (a collective: it is called exactly ``ceil(nq / 8192)`` times whatever path this bank takes)."""
         self._last_flag = None                        # set only by a candidate-mode recall that read its flag
+
+        def drain_exchanges(nq_: int) -> None:
+            # this bank does not take the staged path: keep the shards' collectives matched with neutral bounds
+            if bound_exchange is not None:
+                step = ops.Ivf2Staged.MAX_QUERIES
+                for lo_ in range(0, nq_, step):
+                    bound_exchange[0](torch.full((min(step, nq_ - lo_), 2), -3.0e38, dtype=torch.float32,
+                                                 device=self.device))
         if self.memory_count == 0:
+            drain_exchanges(queries.shape[0])
             z = torch.empty(queries.shape[0], 0, device=self.device)
             return z, z.to(torch.int32)
         q = self._features_to_device(queries)
@@ -593,6 +606,7 @@ class HippocampalFormation(nn.Module):
         kw = dict(count=self.memory_count, loc=self.memory_locations if q_loc is not None else None,
                   q_loc=q_loc, check_overflow=check_overflow)
         if not cand:
+            drain_exchanges(q.shape[0])
             shadow = self._ensure_shadow() if q_loc is None else None
             return ops.knn_search(self.memory_features, self._inv_norm, self.memory_metadata, q, kk, now,
                                   shadow=shadow, rho=self._rho if shadow is not None else None, **kw)
@@ -600,7 +614,8 @@ class HippocampalFormation(nn.Module):
         scores = rows = ovf = None
         full_index = self.centroids.shape[0] == 256
         masked_ok = (q_loc is None and full_index and self.memory_count <= self.MASKED_SCAN_MAX_ROWS and
-                     q.shape[0] <= self.MASKED_SCAN_MAX_QUERIES)
+                     q.shape[0] <= self.MASKED_SCAN_MAX_QUERIES and bound_exchange is None)
+        exchanged = False
         shadow = self._ensure_shadow() if masked_ok else None
         if shadow is not None:
             # up to a few hundred thousand rows the candidate restriction is cheapest as probe masks
@@ -615,7 +630,10 @@ class HippocampalFormation(nn.Module):
             if ivf is not None and not check_overflow and ivf.appended > ivf.slack:
                 ivf.valid = False                     # nobody will read the lists' flag: stay within the proven slack
                 ivf = self._ensure_ivf()
-            if ivf is not None:
+            if ivf is not None and bound_exchange is not None:
+                scores, rows, ovf = self._recall_ivf2_exchanged(q, kk, now, nprobe, ivf, probe_ids, bound_exchange)
+                exchanged = True
+            elif ivf is not None:
                 # large banks / large batches: inverted lists on the two-stage scan (every probed list is
                 # streamed once per 2048 queries from the list-sorted bf16 shadow); same rows and score bits
                 scores, rows, ovf = ops.knn_search_ivf2(self.memory_features, self._inv_norm, self.memory_metadata,
@@ -624,13 +642,15 @@ class HippocampalFormation(nn.Module):
                                                         n_sorted=ivf.n_sorted, lists_flag=ivf.flag,
                                                         probe_ids=probe_ids,
                                                         row_constants=self._ivf_row_constants(ivf, now))
+        if not exchanged:
+            drain_exchanges(q.shape[0])
         if check_overflow and scores is not None:
             # ONE host read for both conditions: the library's flag carries the overflow bits of the
             # two-stage lists and the "a query has no candidate at all" bit
             f = int(ovf.item())
             if f & ops.KNN_FLAG_LISTS_STALE:          # a write outgrew a list's slack: re-pack, then once more
                 self._ivf.valid = False
-                if _retry < 2:
+                if _retry < 2 and bound_exchange is None:   # (an exchanged recall is never repeated: collectives)
                     return self.recall_batch(queries, k=k, locations=locations, now=now, use_candidates=use_candidates,
                                              check_overflow=check_overflow, fallback_empty=fallback_empty,
                                              probe_ids=probe_ids, _retry=_retry + 1)
@@ -665,6 +685,29 @@ class HippocampalFormation(nn.Module):
                                     q[sel].contiguous(), kk, now, **kw2)
             scores[sel], rows[sel] = s2, r2
         return scores, rows
+
+    def _recall_ivf2_exchanged(self, q, kk: int, now: float, nprobe: int, ivf: "_IvfState", probe_ids, bound_exchange):
+        """Inverted-list recall in passes of at most 8192 queries, each in two stages with the shards' bounds
+        combined in between (``aura_knn_search_ivf2_staged``)."""
+        fn, parts = bound_exchange
+        k2 = max(1, -(-kk // max(int(parts), 1)))
+        rowc = self._ivf_row_constants(ivf, now)
+        step = ops.Ivf2Staged.MAX_QUERIES
+        out_s, out_i, flag = [], [], None
+        for lo in range(0, q.shape[0], step):
+            hi = min(q.shape[0], lo + step)
+            st = ops.Ivf2Staged(self.memory_features, self._inv_norm, self.memory_metadata, q[lo:hi].contiguous(), kk, now,
+                                self.centroids, nprobe, ivf.sorted_bf16, self._rho, ivf.sorted_rows, ivf.pad_off,
+                                ivf.list_len, n_sorted=ivf.n_sorted, lists_flag=ivf.flag,
+                                probe_ids=None if probe_ids is None else probe_ids[lo:hi].contiguous(),
+                                row_constants=rowc)
+            bound = fn(st.stage1(k2))
+            s_, i_, f_ = st.stage2(bound.contiguous())
+            if hi - lo == q.shape[0]:
+                return s_, i_, f_
+            out_s.append(s_.clone()); out_i.append(i_.clone())
+            flag = f_.clone() if flag is None else flag.bitwise_or_(f_)   # stage 1 of the next pass resets the flag
+        return torch.cat(out_s), torch.cat(out_i), flag
 
     def probe(self, queries: torch.Tensor) -> Optional[torch.Tensor]:
         """The centroid probes of ``queries`` ([nq, 8] int32, the 8 nearest of the 256 centroid rows in

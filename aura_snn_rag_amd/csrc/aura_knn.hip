@@ -320,7 +320,6 @@ __global__ __launch_bounds__(1024) void online_assign_kernel(float* meta, float*
     __shared__ float s_delta[256], s_counts[256], s_fresh[256];
     __shared__ int s_cand[256];
     __shared__ int s_ncand, s_best;
-    __shared__ float s_dwin;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < 256) {
         s_delta[tid] = 0.0f;
@@ -2430,7 +2429,12 @@ static int knn_search_ivf2_impl(const float* bank, const float* inv_norm, const 
                          int64_t D, int64_t nq, int k,
                          const float* centroids, int nprobe, int32_t idx_base, float* out_scores,
                          int32_t* out_idx, void* workspace, int64_t workspace_bytes,
-                         int32_t* overflow_out, const int32_t* probe_ids, const float4* rowc_cached, void* stream) {
+                         int32_t* overflow_out, const int32_t* probe_ids, const float4* rowc_cached, void* stream,
+                         int stg = 0, int k2 = 0, float* bounds = nullptr) {
+    // stg: 0 = the whole recall; 1 = up to the sampled bounds, written to bounds[nq][2] = {k-th, k2-th largest
+    // sampled lower bound}; 2 = from there on (same workspace, untouched in between), every query's threshold
+    // first raised to bounds[q] (one float per query: the caller's combination of all shards' stage-1 bounds).
+    // Staged calls are single passes (nq <= 8192).
     if (n_sorted <= 0 || N <= 0 || N > 0x7ffffff0LL || D <= 0 || D > 768 || (D & 7) || nq < 0 || k <= 0 ||
         k > COARSE_MAX_K)
         return AURA_E_INVAL;
@@ -2446,6 +2450,7 @@ static int knn_search_ivf2_impl(const float* bank, const float* inv_norm, const 
     if (n_sorted > 0x7ffffff0LL || (n_sorted & 15)) return AURA_E_INVAL;
     const Ivf2Workspace w = carve_ivf2(workspace, n_sorted, nq, k);
     if (w.bytes > workspace_bytes) return AURA_E_INVAL;
+    if (stg != 0 && (nq > w.qp || !bounds || stg < 0 || stg > 2 || k2 < 0 || k2 > k)) return AURA_E_INVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int KS = D <= 256 ? 8 : (D <= 512 ? 16 : 24);
     const float e_fix = aura_e_fix((float)D);                // see aura_knn_coarse.inl
@@ -2479,14 +2484,17 @@ static int knn_search_ivf2_impl(const float* bank, const float* inv_norm, const 
     // creations and the cross-stream waits cost more than the 35 us they hide.)
     const float4* rowc = rowc_cached;
     if (!rowc) {
-        hipLaunchKernelGGL(ivf2_rowc_kernel, dim3((unsigned)((n_sorted + 255) / 256)), dim3(256), 0, s,
-                           meta, rho, sorted_rows, n_sorted, now, (float)D, w.rowc);
-        if ((rc = check_launch())) return rc;
+        if (stg != 2) {
+            hipLaunchKernelGGL(ivf2_rowc_kernel, dim3((unsigned)((n_sorted + 255) / 256)), dim3(256), 0, s,
+                               meta, rho, sorted_rows, n_sorted, now, (float)D, w.rowc);
+            if ((rc = check_launch())) return rc;
+        }
         rowc = w.rowc;
     }
     for (int64_t qb0 = 0; qb0 < nq; qb0 += w.qp) {
         const int nqb = (int)((nq - qb0) < w.qp ? (nq - qb0) : w.qp);
         const float* qptr = queries + qb0 * D;
+        if (stg != 2) {
         // per query: 1/||q||, bf16 fragments, eq; resets of the pass (per-list counters, qslot, the call's flag)
         hipLaunchKernelGGL(ivf2_qprep_kernel, dim3((unsigned)((nqb + 1 + 3) / 4)), dim3(256), 0, s,
                            qptr, (int64_t)nqb, D, KS, w.qhat, w.inv_q, w.eq_q, w.qslot, w.lq_cnt,
@@ -2512,6 +2520,7 @@ static int knn_search_ivf2_impl(const float* bank, const float* inv_norm, const 
                            w.eq_slot);
         if ((rc = check_launch())) return rc;
         stage("slots");
+        }
 
         CoarseArgs c{};
         c.bank = bank; c.bank16 = sorted_bf16; c.rowc = rowc; c.qhat = w.qhat; c.inv_q = w.inv_q;
@@ -2533,12 +2542,13 @@ static int knn_search_ivf2_impl(const float* bank, const float* inv_norm, const 
             if (KS == 16) return launch_coarse_ivf<16, 8>(c, mode, cus, s);
             return launch_coarse_ivf<24, 8>(c, mode, cus, s);
         };
+        if (stg != 2) {
         if ((rc = launch(CS_MODE_SAMPLE))) return rc;
         stage("sample scan");
         {
             const dim3 tg((unsigned)((nqb + 3) / 4)), tb(256);
 #define AURA_THR2(PER) hipLaunchKernelGGL((ivf2_threshold_kernel<PER>), tg, tb, 0, s, w.gmax, w.qslot, w.blk_list, list_len, \
-                                          nprobe, k, nqb, w.thr, w.cnt)
+                                          nprobe, k, nqb, w.thr, w.cnt, stg == 1 ? k2 : 0, stg == 1 ? bounds : nullptr)
             if (stiles == 32) AURA_THR2(8);
             else if (stiles == 64) AURA_THR2(16);
             else if (stiles == 128) AURA_THR2(32);
@@ -2547,6 +2557,14 @@ static int knn_search_ivf2_impl(const float* bank, const float* inv_norm, const 
         }
         if ((rc = check_launch())) return rc;
         stage("threshold");
+        if (stg == 1) return AURA_OK;
+        } else {
+            // the caller's bound (e.g. combined over the shards of a row-sharded bank) tightens the thresholds
+            hipLaunchKernelGGL(ivf2_raise_thr_kernel, dim3((unsigned)ivf2_maxblk(w.qp)), dim3(256), 0, s,
+                               w.slotq, w.nblk, bounds, w.thr);
+            if ((rc = check_launch())) return rc;
+            stage("raise thresholds");
+        }
         c.gmax = nullptr; c.item_off = w.item_off;
         static int tm_left2 = 2;                             // AURA_CS_DBG bit 64: phase times of the first launches
         const bool tm2 = (cs_dbg & 64) && tm_left2 > 0;
@@ -2663,6 +2681,22 @@ int aura_knn_search_ivf2_probed(const float* bank, const float* inv_norm, const 
                                 n_sorted, N, queries, now, D, nq, k, centroids, nprobe, idx_base, out_scores, out_idx,
                                 workspace, workspace_bytes, overflow_out, probe_ids,
                                 reinterpret_cast<const float4*>(row_constants), stream);
+}
+
+int aura_knn_search_ivf2_staged(const float* bank, const float* inv_norm, const float* meta,
+                                const uint16_t* sorted_bf16, const float* rho, const int32_t* sorted_rows,
+                                const int32_t* pad_off, const int32_t* list_len, const int32_t* lists_flag,
+                                const float* row_constants,
+                                int64_t n_sorted, int64_t N, const float* queries, float now, int64_t D, int64_t nq,
+                                int k, const float* centroids, int nprobe, const int32_t* probe_ids, int32_t idx_base,
+                                float* out_scores, int32_t* out_idx, void* workspace, int64_t workspace_bytes,
+                                int32_t* overflow_out, int stage, int k2, float* bounds, void* stream) {
+    if (stage != 1 && stage != 2) return AURA_E_INVAL;
+    if (reinterpret_cast<uintptr_t>(row_constants) & 15) return AURA_E_ALIGN;
+    return knn_search_ivf2_impl(bank, inv_norm, meta, sorted_bf16, rho, sorted_rows, pad_off, list_len, lists_flag,
+                                n_sorted, N, queries, now, D, nq, k, centroids, nprobe, idx_base, out_scores, out_idx,
+                                workspace, workspace_bytes, overflow_out, probe_ids,
+                                reinterpret_cast<const float4*>(row_constants), stream, stage, k2, bounds);
 }
 
 int aura_knn_search(const float* bank, const float* inv_norm, const float* meta, const float* loc,

@@ -234,7 +234,8 @@ __global__ __launch_bounds__(256) void ivf2_threshold_kernel(const float* __rest
                                                              const int32_t* __restrict__ list_len,
                                                              int nprobe, int k, int nq,
                                                              uint32_t* __restrict__ thr,
-                                                             int32_t* __restrict__ cnt_out) {
+                                                             int32_t* __restrict__ cnt_out,
+                                                             int k2, float* __restrict__ bounds) {   // staged recall: bounds[q] = {T_k, T_k2}
     const int lane = threadIdx.x & 63;
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= nq) return;
@@ -271,6 +272,39 @@ __global__ __launch_bounds__(256) void ivf2_threshold_kernel(const float* __rest
     if (T < 0x00800000u) T = 0x00800000u;                  // ord_key(-FLT_MAX): real rows pass, pads (-inf) do not
     if (vs >= 0 && (lane & 7) == 0) thr[vs] = T;
     if (lane == 0) cnt_out[(int64_t)q * CNT_STRIDE] = 0;
+    if (bounds) {
+        // k2-th largest sampled lower bound: at least k2 DISTINCT rows of this bank score >= it, so over S
+        // disjoint shards the minimum of the shards' values is a lower bound of the (S k2)-th best score
+        uint32_t T2 = T;
+        if (k2 > 0 && k2 < k) {
+            T2 = 0u;
+            for (int bit = 31; bit >= 0; --bit) {
+                const uint32_t cand = T2 | (1u << bit);
+                int c = 0;
+#pragma unroll
+                for (int i = 0; i < PER; ++i) c += __popcll(__ballot(key[i] >= cand));
+                if (c >= k2) T2 = cand;
+            }
+            if (T2 < 0x00800000u) T2 = 0x00800000u;
+        }
+        if (lane == 0) { bounds[(int64_t)q * 2] = ord_unkey(T); bounds[(int64_t)q * 2 + 1] = ord_unkey(T2); }
+    }
+}
+
+// staged recall, stage 2: thr[slot] = max(thr[slot], bound of the slot's query) (ordered keys: larger = larger)
+__global__ __launch_bounds__(256) void ivf2_raise_thr_kernel(const int32_t* __restrict__ slotq,
+                                                             const int32_t* __restrict__ nblk,
+                                                             const float* __restrict__ bound_q,
+                                                             uint32_t* __restrict__ thr) {
+    const int64_t vs = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if ((int)(vs >> 8) >= nblk[0]) return;
+    const int q = slotq[vs];
+    if (q < 0) return;
+    const float b = bound_q[q];
+    if (!(b == b) || b == INFINITY) return;                 // never trust a NaN / +inf bound
+    uint32_t kq = ord_key(b);
+    if (kq < 0x00800000u) kq = 0x00800000u;
+    if (kq > thr[vs]) thr[vs] = kq;
 }
 
 struct Ivf2Workspace {

@@ -675,6 +675,76 @@ def knn_search_ivf2(bank, inv_norm, meta, queries, k: int, now: float, centroids
     return out_s, out_i, ovf
 
 
+class Ivf2Staged:
+    """``knn_search_ivf2`` in two stages (``aura_knn_search_ivf2_staged``) for one pass of at most 8192 queries:
+    ``stage1(k2)`` -> bounds [nq, 2] (the k-th and the k2-th largest sampled lower bound of every query on this
+    bank), ``stage2(bound [nq])`` -> (scores, idx, overflow flag) with every threshold raised to ``bound`` first.
+    Between the two calls the caller combines the bounds of all shards of a row-sharded bank; nothing else may
+    use this stream's kNN workspace in between."""
+
+    MAX_QUERIES = 8192
+
+    def __init__(self, bank, inv_norm, meta, queries, k: int, now: float, centroids, nprobe: int,
+                 sorted_shadow, rho, sorted_rows, pad_off, list_len, idx_base: int = 0,
+                 n_sorted: Optional[int] = None, lists_flag=None, probe_ids=None, row_constants=None):
+        _need(bank, "bank", torch.float32); _need(inv_norm, "inv_norm", torch.float32)
+        _need(meta, "meta", torch.float32); _need(queries, "queries", torch.float32)
+        _need(centroids, "centroids", torch.float32); _need(sorted_shadow, "sorted_shadow", torch.bfloat16)
+        _need(rho, "rho", torch.float32)
+        for t, n in ((sorted_rows, "sorted_rows"), (pad_off, "pad_off"), (list_len, "list_len")):
+            _need(t, n, torch.int32)
+        M, D = bank.shape
+        nq = queries.shape[0]
+        ns = sorted_rows.numel() if n_sorted is None else int(n_sorted)
+        if queries.dim() != 2 or queries.shape[1] != D or meta.shape != (M, 4) or rho.numel() != M or \
+                not (0 < nq <= self.MAX_QUERIES):
+            raise ValueError("Ivf2Staged: shape mismatch (1..8192 queries per staged pass)")
+        if centroids.shape != (256, D) or not (0 < nprobe <= 8) or not (0 < k <= 256) or D % 8 or D > 768:
+            raise ValueError("Ivf2Staged: centroids [256, D], nprobe <= 8, k <= 256, D % 8 == 0, D <= 768")
+        if sorted_shadow.shape[1] != D or not (0 < ns <= min(sorted_rows.numel(), sorted_shadow.shape[0])) or \
+                pad_off.numel() != 257 or list_len.numel() != 256 or ns % 16:
+            raise ValueError("Ivf2Staged: layout arrays do not match")
+        if lists_flag is not None:
+            _need(lists_flag, "lists_flag", torch.int32)
+        if row_constants is not None:
+            _need(row_constants, "row_constants", torch.float32)
+            if row_constants.dim() != 2 or row_constants.shape[1] != 4 or row_constants.shape[0] < ns:
+                raise ValueError("Ivf2Staged: row_constants must be [>= n_sorted, 4]")
+        if probe_ids is not None:
+            _need(probe_ids, "probe_ids", torch.int32)
+            if tuple(probe_ids.shape) != (nq, 8):
+                raise ValueError("Ivf2Staged: probe_ids must be [nq, 8]")
+        dev = bank.device
+        self._keep = (bank, inv_norm, meta, queries, centroids, sorted_shadow, rho, sorted_rows, pad_off, list_len,
+                      lists_flag, probe_ids, row_constants)
+        self.nq, self.k = nq, int(k)
+        self.out_s = torch.empty(nq, k, dtype=torch.float32, device=dev)
+        self.out_i = torch.empty(nq, k, dtype=torch.int32, device=dev)
+        self.ovf = _overflow_flag(dev)
+        L = lib()
+        self._nbytes = L.aura_knn_ivf2_workspace_bytes(ns, nq, k)
+        self._ws = _workspace(dev, self._nbytes)
+        base = (self._ws.data_ptr() + 255) // 256 * 256
+        self._call = lambda stage, k2, bounds: check(
+            L.aura_knn_search_ivf2_staged(_p(bank), _p(inv_norm), _p(meta), _p(sorted_shadow), _p(rho), _p(sorted_rows),
+                                          _p(pad_off), _p(list_len), _p(lists_flag), _p(row_constants), ns, M,
+                                          _p(queries), now, D, nq, k, _p(centroids), nprobe, _p(probe_ids), idx_base,
+                                          _p(self.out_s), _p(self.out_i), base, self._nbytes, _p(self.ovf), stage, k2,
+                                          _p(bounds), _stream()), "aura_knn_search_ivf2_staged")
+
+    def stage1(self, k2: int = 0) -> torch.Tensor:
+        b = torch.empty(self.nq, 2, dtype=torch.float32, device=self.out_s.device)
+        self._call(1, int(k2), b)
+        return b
+
+    def stage2(self, bound: torch.Tensor):
+        _need(bound, "bound", torch.float32)
+        if bound.numel() != self.nq:
+            raise ValueError("Ivf2Staged.stage2: one bound per query")
+        self._call(2, 0, bound)
+        return self.out_s, self.out_i, self.ovf
+
+
 def topk_merge(scores, idx, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
     """scores, idx: [S, nq, k] per-shard lists -> merged (scores [nq, k], idx [nq, k])."""
     _need(scores, "scores", torch.float32); _need(idx, "idx", torch.int32)

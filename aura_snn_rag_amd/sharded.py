@@ -39,10 +39,13 @@ class ShardedRecall:
     that the same host logic runs on the HIP ops (product) and on CPU stand-ins in the gloo tests.
     """
 
-    def __init__(self, local_search: Callable, merge: Callable, group=None):
+    def __init__(self, local_search: Callable, merge: Callable, group=None, force_collectives: bool = False):
         self.local_search = local_search
         self.merge = merge
         self.group = group
+        # run the gather + merge even with one shard (tests: the collectives' packing and RCCL itself are
+        # exercised on a one-GPU box)
+        self.force_collectives = force_collectives
 
     @property
     def world(self) -> int:
@@ -56,7 +59,7 @@ class ShardedRecall:
                ) -> Tuple[torch.Tensor, torch.Tensor]:
         S = self.world
         nq = queries.shape[0]
-        if not dist.is_initialized() or S == 1:
+        if not dist.is_initialized() or (S == 1 and not self.force_collectives):
             return self.local_search(queries, k)     # one shard: its sorted top-k is the result
         if all_gather_queries:
             allq = torch.empty(S * nq, queries.shape[1], dtype=queries.dtype, device=queries.device)
@@ -100,7 +103,8 @@ class ShardedHippocampus:
 
     ``ops`` is injected (the HIP ops in the product, the CPU stand-ins in the gloo tests)."""
 
-    def __init__(self, local, total_rows: int, ops_module=None, group=None, now_fn=None):
+    def __init__(self, local, total_rows: int, ops_module=None, group=None, now_fn=None,
+                 force_collectives: bool = False, exchange_bounds: bool = True):
         import time as _time
         from . import ops as _ops
         self.local = local
@@ -116,14 +120,32 @@ class ShardedHippocampus:
         self.memory_count = 0                      # global
         self._write_cursor = 0
         self._now = _time.time if now_fn is None else now_fn
-        self._recall = ShardedRecall(self._local_search, self.ops.topk_merge, group)
+        # force_collectives: every collective runs even at world size 1 (a one-GPU box then exercises the
+        # packing, the merge and RCCL itself); exchange_bounds: the shards' sampled recall bounds are combined
+        # before any shard filters (see recall_batch)
+        self.force_collectives = bool(force_collectives) and dist.is_initialized()
+        self.exchange_bounds = bool(exchange_bounds)
+        self._recall = ShardedRecall(self._local_search, self.ops.topk_merge, group, self.force_collectives)
         self._recall_kw = {}
+        self._epoch = 0                            # bumped by every collective mutation (write, bulk_write, rebuild)
+        self._exch_epoch = -1                      # epoch for which _exch_ok was agreed
+        self._exch_ok = False
+        self._check_layout = False                 # bulk_write ran: the next write() verifies the shard fill
+        self._scratch = None                       # write(): scratch bank of the replicated centroid update
+        self.exchanges = 0                         # bound exchanges performed (tests / diagnostics)
 
     # ------------------------------------------------------------------ helpers
-    def _all_reduce(self, t: torch.Tensor) -> torch.Tensor:
-        if self.world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+    def _collective(self) -> bool:
+        return self.world > 1 or self.force_collectives
+
+    def _all_reduce(self, t: torch.Tensor, op=None) -> torch.Tensor:
+        if self._collective():
+            dist.all_reduce(t, op=dist.ReduceOp.SUM if op is None else op, group=self.group)
         return t
+
+    def _src0(self) -> int:
+        """Global rank of the group's rank 0 (``dist.broadcast`` takes global ranks)."""
+        return dist.get_global_rank(self.group, 0) if self.group is not None else 0
 
     def _local_count(self, global_count: int) -> int:
         return max(0, min(self.R, global_count - self.row_base))
@@ -143,6 +165,19 @@ class ShardedHippocampus:
         if feats.shape[0] != n:
             raise ValueError(f"{n} ids but {feats.shape[0]} feature rows")
         M = self.total_rows
+        if self._check_layout:
+            # bulk_write fills shards independently; the slot-ordered path below needs shard g to hold exactly
+            # clamp(count - g R, 0, R) rows.  Checked COLLECTIVELY, so that every rank raises (a rank that
+            # raised alone would leave the others hanging in the next collective).
+            ok = torch.tensor([1 if loc.memory_count == self._local_count(self.memory_count) else 0],
+                              dtype=torch.int64, device=loc.memory_features.device)
+            ok = int(self._all_reduce(ok, dist.ReduceOp.MIN).item()) if self._collective() else int(ok.item())
+            if not ok:
+                raise RuntimeError("ShardedHippocampus.write after bulk_write: the shards are not filled in slot order "
+                                   "(shard g must hold clamp(count - g R, 0, R) rows); fill every shard completely or "
+                                   "keep using bulk_write")
+            self._check_layout = False
+        self._epoch += 1
         i = 0
         while i < n:
             run = n - i
@@ -172,14 +207,17 @@ class ShardedHippocampus:
                 # rows pass through a scratch bank (only their centroid ids and the table's new state matter)
                 dev, D = feats.device, feats.shape[1]
                 sd = loc.memory_locations.shape[1]
-                s_bank = torch.empty(run, D, device=dev); s_loc = torch.empty(run, sd, device=dev)
-                s_meta = torch.empty(run, 4, device=dev); s_inv = torch.empty(run, device=dev)
-                self.ops.bank_write(s_bank, s_loc, s_meta, s_inv, f_r.contiguous(),
-                                    torch.arange(run, dtype=torch.int64, device=dev),
+                sc = self._scratch
+                if sc is None or sc[0].shape[0] < run or sc[0].device != dev:
+                    cap = max(run, int(loc.centroids_update_interval))
+                    sc = self._scratch = (torch.empty(cap, D, device=dev), torch.empty(cap, sd, device=dev),
+                                          torch.empty(cap, 4, device=dev), torch.empty(cap, device=dev),
+                                          torch.arange(cap, dtype=torch.int64, device=dev))
+                self.ops.bank_write(sc[0], sc[1], sc[2], sc[3], f_r.contiguous(), sc[4][:run],
                                     loc.current_location.to(device=dev, dtype=torch.float32).contiguous(), now,
                                     centroids=loc.centroids, centroid_counts=loc.centroid_counts,
-                                    eff_k=min(loc.centroids_k, loc.centroids.shape[0]))
-                cids = s_meta[:, 2].contiguous()
+                                    eff_k=min(loc.centroids_k, loc.centroids.shape[0]), distinct_slots=True)
+                cids = sc[2][:run, 2].contiguous()
             own = (slots // self.R) == self.rank
             if own.any():
                 idx = np.nonzero(own)[0]
@@ -197,10 +235,14 @@ class ShardedHippocampus:
         """Seeding path: every rank passes ITS OWN rows (already routed: e.g. rank g reads the g-th slice
         of the corpus); rows are appended to the local shard, no centroid update.  Returns the new global
         count; call ``rebuild_centroids`` once at the end.  Shards must be filled evenly by the caller
-        (global row ids are ``rank * R + local row``)."""
+        (global row ids are ``rank * R + local row``).  ``write`` plans slots globally (slot // R owns the row),
+        which only agrees with independently filled shards once every shard before the last non-empty one is
+        full; the first ``write`` after a ``bulk_write`` checks that collectively and raises on every rank."""
         self.local.bulk_write(features, id_prefix=id_prefix, first_index=first_index, rebuild=False)
-        c = torch.tensor([float(self.local.memory_count)], device=self.local.memory_features.device)
+        c = torch.tensor([self.local.memory_count], dtype=torch.int64, device=self.local.memory_features.device)
         self.memory_count = int(self._all_reduce(c).item())
+        self._epoch += 1
+        self._check_layout = True                  # write() plans slots globally: only valid for slot-ordered shards
         return self.memory_count
 
     # ------------------------------------------------------------------ rebuild
@@ -212,20 +254,23 @@ class ShardedHippocampus:
         n_loc = loc.memory_count
         # global row ids of the local rows; with evenly filled shards (bulk_write) the global count is
         # world * n_loc, with the slot-ordered write path it is self.memory_count
-        n_glob = int(self._all_reduce(torch.tensor([float(n_loc)], device=dev)).item())
+        self._epoch += 1
+        counts_all = torch.zeros(self.world, dtype=torch.int64, device=dev)   # int64: exact beyond 2^24 rows
+        counts_all[self.rank] = n_loc
+        counts_all = self._all_reduce(counts_all).cpu()
+        n_glob = int(counts_all.sum().item())
         if n_glob == 0:
             return
         k = min(loc.centroids_k, n_glob)
         if perm is None:
             perm = torch.randperm(n_glob)
-            if self.world > 1:                     # rank 0's draw, as one process would draw it
+            if self._collective():                 # rank 0's draw, as one process would draw it
                 p = perm.to(dev)
-                dist.broadcast(p, src=0, group=self.group)
+                dist.broadcast(p, src=self._src0(), group=self.group)
                 perm = p.cpu()
+        if perm.numel() < k:
+            raise ValueError(f"rebuild_centroids: perm has {perm.numel()} entries, {k} initial rows are needed")
         # initial centroids: perm indexes the ACTIVE rows in global order (shard after shard)
-        counts_all = torch.zeros(self.world, device=dev)
-        counts_all[self.rank] = float(n_loc)
-        counts_all = self._all_reduce(counts_all).long().cpu()
         starts = torch.cumsum(counts_all, 0) - counts_all          # first active index of every rank
         pk = perm[:k].long()
         mine = (pk >= starts[self.rank]) & (pk < starts[self.rank] + n_loc)
@@ -280,6 +325,46 @@ class ShardedHippocampus:
             s = torch.where(r >= 0, s, torch.full_like(s, float("-inf")))
         return s.contiguous(), r.contiguous()
 
+    def _exchange(self, b: torch.Tensor) -> torch.Tensor:
+        """bounds [n, 2] = {k-th, ceil(k/S)-th largest sampled lower bound on this shard} -> the combined bound
+        [n]: max(max over shards of column 0, min over shards of column 1), one all-reduce(MAX)."""
+        v = torch.stack([b[:, 0], -b[:, 1]], dim=1).contiguous()
+        dist.all_reduce(v, op=dist.ReduceOp.MAX, group=self.group)
+        self.exchanges += 1
+        return torch.maximum(v[:, 0], -v[:, 1]).contiguous()
+
+    def _exchange_agreed(self) -> bool:
+        """Can EVERY shard run the staged inverted-list recall?  (Agreed by one all-reduce per mutation epoch.)"""
+        if self._exch_epoch != self._epoch:
+            loc = self.local
+            ok = bool(loc._candidate_mode() and loc._shadow_applies() and loc.centroids.shape[0] == 256
+                      and loc.memory_features.shape[1] % 8 == 0 and loc.memory_features.shape[1] <= 768
+                      and loc.memory_count >= 256)
+            t = torch.tensor([1 if ok else 0], dtype=torch.int64, device=loc.memory_features.device)
+            self._exch_ok = bool(int(self._all_reduce(t, dist.ReduceOp.MIN).item()))
+            self._exch_epoch = self._epoch
+        return self._exch_ok
+
+    # ------------------------------------------------------------------ persistence (SURVEY 8f-3, sharded)
+    def bank_state(self) -> dict:
+        """Host-side state of THIS rank's shard plus the global counters (``HippocampalFormation.bank_state``);
+        save it per rank beside ``local.state_dict()``."""
+        return {"world": self.world, "rank": self.rank, "rows_per_rank": self.R, "total_rows": self.total_rows,
+                "memory_count": self.memory_count, "write_cursor": self._write_cursor,
+                "local": self.local.bank_state()}
+
+    def load_bank_state(self, state: dict) -> None:
+        """Inverse of ``bank_state`` (after ``local.load_state_dict``); the sharding must be the one saved."""
+        if (int(state["world"]), int(state["rank"]), int(state["rows_per_rank"])) != (self.world, self.rank, self.R):
+            raise ValueError("sharded bank_state: saved for rank %s of %s with %s rows per rank" %
+                             (state["rank"], state["world"], state["rows_per_rank"]))
+        self.local.load_bank_state(state["local"])
+        self.total_rows = int(state["total_rows"])
+        self.memory_count = int(state["memory_count"])
+        self._write_cursor = int(state["write_cursor"])
+        self._epoch += 1
+        self._check_layout = False
+
     def recall_batch(self, queries: torch.Tensor, k: int = 5, now: Optional[float] = None,
                      all_gather_queries: bool = False, use_candidates: Optional[bool] = None,
                      check_overflow: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -295,7 +380,17 @@ class ShardedHippocampus:
         loc0 = self.local
         cand = bool(use_candidates is not False and getattr(loc0, "use_centroid_index", False)
                     and getattr(loc0, "_index_ready", False) and self.memory_count > loc0.centroids_k)
-        if all_gather_queries and self.world > 1:
+        # The shards' sampled bounds are combined before any shard filters: a shard's
+        # threshold for a query is a lower bound of the query's k-th best score over the WHOLE bank -- the k-th
+        # largest sampled lower bound on any one shard is, and so is the minimum over the S shards of their
+        # ceil(k / S)-th largest (S disjoint shards x ceil(k / S) distinct rows each).  One all-reduce(MAX) of
+        # nq x 2 floats per pass of 8192 queries; every shard then keeps ~1/S of the candidates and survivors
+        # it would keep against its own bound.  Whether the staged path is taken is agreed collectively once
+        # per mutation epoch (every shard must be able to run it), never per call.
+        if cand and self.exchange_bounds and self._collective() and int(k) <= 256 and hasattr(self.ops, "Ivf2Staged") \
+                and self._exchange_agreed():
+            self._recall_kw["bound_exchange"] = (self._exchange, self.world)
+        if all_gather_queries and self._collective():
             # every rank sees every query block: the merged result (and the empty-candidate decision
             # below) is then identical on all ranks, so the fallback stays collective-safe.  The centroid
             # table is replicated, so each query is probed ONCE, by the rank that brings it, and its probes
@@ -330,6 +425,7 @@ class ShardedHippocampus:
             sel = torch.nonzero(r[:, 0] < 0).flatten()
             self._recall_kw["use_candidates"] = False
             self._recall_kw.pop("probe_ids", None)
+            self._recall_kw.pop("bound_exchange", None)
             s2, r2 = self._recall.recall(allq[sel].contiguous(), int(k))
             s[sel], r[sel] = s2, r2
         if allq is not q:

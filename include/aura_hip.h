@@ -318,6 +318,26 @@ int aura_knn_search_ivf2_probed(const float* bank, const float* inv_norm, const 
                                 float* out_scores, int32_t* out_idx, void* workspace, int64_t workspace_bytes,
                                 int32_t* overflow_out, void* stream);
 
+/* aura_knn_search_ivf2[_probed] in two stages, for a bank that is row-sharded over ranks: the
+ * prefilter's threshold of a query is a lower bound of its k-th best score, and bounds found on different
+ * shards can be combined before any shard filters -- every shard then keeps about 1/S of the candidates
+ * and survivors it would keep against its own bound.
+ *   stage 1: everything up to the sampled bounds; bounds[q][0] = the k-th, bounds[q][1] = the k2-th
+ *            (1 <= k2 <= k; 0: same as k) largest sampled lower bound of query q on THIS bank: at least k
+ *            (k2) distinct rows of this bank score at least that.
+ *   stage 2: same arguments, same workspace (untouched in between), bounds[q] = ONE float per query: any valid
+ *            lower bound of the query's global k-th best score, e.g. max(max over shards of bounds[.][0],
+ *            min over shards of bounds[.][1]) with S k2 >= k; thresholds are raised to it, then filter + refine.
+ * probe_ids may be NULL (probes computed in stage 1).  nq <= 8192 per staged call. */
+int aura_knn_search_ivf2_staged(const float* bank, const float* inv_norm, const float* meta,
+                                const uint16_t* sorted_bf16, const float* rho, const int32_t* sorted_rows,
+                                const int32_t* pad_off, const int32_t* list_len, const int32_t* lists_flag,
+                                const float* row_constants,
+                                int64_t n_sorted, int64_t N, const float* queries, float now, int64_t D, int64_t nq,
+                                int k, const float* centroids, int nprobe, const int32_t* probe_ids, int32_t idx_base,
+                                float* out_scores, int32_t* out_idx, void* workspace, int64_t workspace_bytes,
+                                int32_t* overflow_out, int stage, int k2, float* bounds, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Surrogate-gradient training path and the prosody-modulated GIF (fp32, [rows][T][H] layout)
  * ------------------------------------------------------------------------------------- */

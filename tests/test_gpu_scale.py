@@ -160,7 +160,7 @@ def _sharded_gpu_worker(rank, world, port, out):
     s_e, r_e = sh.recall_batch(q.to(dev), k=9, now=now[0], use_candidates=False)
     myq = q[rank * 350:(rank + 1) * 350].to(dev).contiguous()
     s_o, r_o = sh.recall_batch(myq, k=9, now=now[0], all_gather_queries=True)
-    torch.save(dict(count=sh.memory_count, local=local.memory_count, cent=local.centroids.cpu(),
+    torch.save(dict(count=sh.memory_count, local=local.memory_count, cent=local.centroids.cpu(), exchanges=sh.exchanges,
                     res=[t.cpu() for t in (s_c, r_c, s_e, r_e)], own=(s_o.cpu(), r_o.cpu()),
                     meta=local.memory_metadata.cpu()), out + f".{rank}")
     dist.barrier()
@@ -195,6 +195,7 @@ def test_sharded_bank_on_hip_kernels_two_ranks_one_gpu(dev, tmp_path):
     s_c, r_c = hf.recall_batch(q, k=9, now=1.7e9)
     s_e, r_e = hf.recall_batch(q, k=9, now=1.7e9, use_candidates=False)
     assert parts[0]["count"] == 20300 and [p["local"] for p in parts] == [12000, 8300]
+    assert all(p["exchanges"] >= 2 for p in parts), "the shards' bounds were not exchanged"
     assert torch.equal(parts[0]["cent"], parts[1]["cent"])
     assert torch.allclose(parts[0]["cent"], hf.centroids.cpu(), rtol=1e-5, atol=1e-5)
     meta = torch.cat([p["meta"] for p in parts])

@@ -164,3 +164,85 @@ def test_two_rank_sharded_writes_rebuild_and_candidate_recall(tmp_path, monkeypa
     for r in range(2):
         s_o, r_o = parts[r]["own"]
         assert torch.equal(r_o.long(), r_c[r * 7:(r + 1) * 7].long())
+
+
+# ----------------------------------------------------------------------------------------------
+# Seeding path of the sharded bank (BASELINE config 5): every rank bulk-writes ITS OWN rows, one
+# collective rebuild, recall -- against ONE bank holding the shards side by side; the shard-fill
+# check of write() after bulk_write; persistence of a sharded bank.
+# ----------------------------------------------------------------------------------------------
+def _bulk_worker(rank, world, port, out):
+    from aura_snn_rag_amd.core import hippocampal as H
+    from aura_snn_rag_amd.sharded import ShardedHippocampus
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    H.ops = stub
+    H.time.time = lambda: NOW
+    D, R, ck = 16, 500, 16
+    rows = _clustered_rows(2 * R, D, 11)
+    q = _clustered_rows(12, D, 12)
+    perm = torch.randperm(2 * R, generator=torch.Generator().manual_seed(13))
+    local = H.HippocampalFormation(**_bank_kw(D, R))
+    local.centroids_k, local.centroids_update_interval = ck, 10 ** 9
+    sh = ShardedHippocampus(local, 2 * R, ops_module=stub, now_fn=lambda: NOW)
+    # a partly filled pair of shards first: write() must refuse it ON EVERY RANK (300 + 300 rows: rank 1 should
+    # hold none of the first 600 slots)
+    part = ShardedHippocampus(H.HippocampalFormation(**_bank_kw(D, R)), 2 * R, ops_module=stub, now_fn=lambda: NOW)
+    part.local.centroids_k = ck
+    assert part.bulk_write(rows[rank * 300:(rank + 1) * 300]) == 600
+    raised = False
+    try:
+        part.write(["a", "b"], rows[:2])
+    except RuntimeError:
+        raised = True
+    # the seeding path proper: full shards
+    assert sh.bulk_write(rows[rank * R:(rank + 1) * R]) == 2 * R
+    sh.rebuild_centroids(perm=perm)
+    s_c, r_c = sh.recall_batch(q, k=6, now=NOW)
+    s_e, r_e = sh.recall_batch(q, k=6, now=NOW, use_candidates=False)
+    cent0, counts0 = local.centroids.clone(), local.centroid_counts.clone()
+    # a write after the full seeding: the ring overwrites global slots 0.. (consistent layout: no error)
+    sh.write([f"w{i}" for i in range(5)], rows[:5] + 0.01)
+    # persistence: state dict + bank_state into a fresh pair of objects, same recall
+    sd, bs = {k_: v.clone() for k_, v in local.state_dict().items()}, sh.bank_state()
+    local2 = H.HippocampalFormation(**_bank_kw(D, R))
+    local2.centroid_counts = torch.zeros(ck)                    # (this test shrinks centroids_k: the counts buffer follows)
+    local2.load_state_dict(sd)
+    sh2 = ShardedHippocampus(local2, 2 * R, ops_module=stub, now_fn=lambda: NOW)
+    sh2.load_bank_state(bs)
+    s_a, r_a = sh.recall_batch(q, k=6, now=NOW)
+    s_b, r_b = sh2.recall_batch(q, k=6, now=NOW)
+    torch.save(dict(raised=raised, res=(s_c, r_c, s_e, r_e), cent=cent0, counts=counts0,
+                    meta=local.memory_metadata.clone(), reload_equal=bool(torch.equal(r_a, r_b) and torch.equal(s_a, s_b)),
+                    count2=sh2.memory_count, cursor2=sh2._write_cursor, cursor=sh._write_cursor,
+                    id5=local2.id_of_row(4) if rank == 0 else None), out + f".{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_bulk_write_rebuild_recall_and_persistence(tmp_path, monkeypatch):
+    out = str(tmp_path / "bulk")
+    mp.spawn(_bulk_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    from aura_snn_rag_amd.core import hippocampal as H
+    monkeypatch.setattr(H, "ops", stub)
+    monkeypatch.setattr(H.time, "time", lambda: NOW)
+    D, R, ck = 16, 500, 16
+    rows = _clustered_rows(2 * R, D, 11)
+    q = _clustered_rows(12, D, 12)
+    perm = torch.randperm(2 * R, generator=torch.Generator().manual_seed(13))
+    hf = H.HippocampalFormation(**_bank_kw(D, 2 * R))
+    hf.centroids_k, hf.centroids_update_interval = ck, 10 ** 9
+    hf.bulk_write(rows, rebuild=False)
+    hf.rebuild_centroids(perm=perm)
+    s_c, r_c = hf.recall_batch(q, k=6, now=NOW)
+    s_e, r_e = hf.recall_batch(q, k=6, now=NOW, use_candidates=False)
+    parts = [torch.load(out + f".{r}") for r in range(2)]
+    assert all(p["raised"] for p in parts), "write() after an uneven bulk_write must raise on every rank"
+    assert torch.equal(parts[0]["cent"], parts[1]["cent"]) and torch.equal(parts[0]["counts"], parts[1]["counts"])
+    assert torch.allclose(parts[0]["cent"], hf.centroids, rtol=1e-5, atol=1e-5)
+    ps_c, pr_c, ps_e, pr_e = parts[0]["res"]
+    assert torch.equal(pr_e.long(), r_e.long()) and torch.allclose(ps_e, s_e, atol=1e-6)
+    assert torch.equal(pr_c.long(), r_c.long()) and torch.allclose(ps_c, s_c, atol=1e-6)
+    for p in parts:
+        assert p["reload_equal"] and p["count2"] == 2 * R and p["cursor2"] == p["cursor"] == 5
+    assert parts[0]["id5"] == "w4"                               # the ring overwrote global slots 0..4 (rank 0's)
