@@ -1063,9 +1063,11 @@ constexpr int PR_Q = 16;                   // queries per workgroup
 constexpr int PR_WAVES = 8;                // waves per workgroup: wave w owns centroids [32 w, 32 w + 32)
 constexpr int PR_T = 256 / PR_WAVES / 16;  // 16 x 16 output tiles per wave
 constexpr int PR_G = 4;                    // k-groups (16 k each) per software-pipeline stage
+constexpr int PR_QLDS_MAX_D = 2048;        // query tile in LDS up to this many columns (16 x 2052 x 4 B = 128 KiB)
 constexpr int PR_KSTRIDE = 260;            // floats per key row in LDS (260 % 32 = 4: the four query groups of a
                                            // wave read different banks)
 
+template <bool QLDS>                       // the workgroup's 16 queries staged in LDS once (D <= PR_QLDS_MAX_D)
 __global__ __launch_bounds__(64 * PR_WAVES) void centroid_probe_kernel(const float* __restrict__ centroids,
                                                              const float* __restrict__ queries,
                                                              int64_t D, int nq, int nprobe,
@@ -1074,10 +1076,13 @@ __global__ __launch_bounds__(64 * PR_WAVES) void centroid_probe_kernel(const flo
                                                              int32_t* __restrict__ lq_cnt,
                                                              int32_t* __restrict__ lq_list, int lq_stride) {
     __shared__ float s_key[PR_Q * PR_KSTRIDE];
+    extern __shared__ __attribute__((aligned(16))) float s_qt[];   // QLDS: [16][D16 + 4] query tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, h = lane >> 4;
     const int q0 = blockIdx.x * PR_Q;
     const int c0 = wave * (16 * PR_T);
+    const int64_t D16 = (D + 15) / 16 * 16;
+    const int64_t QS = D16 + 4;                               // row stride: 16 rows x ds_read_b128 hit 64 different banks
     const bool vec = (D & 3) == 0 && ((reinterpret_cast<uintptr_t>(queries) | reinterpret_cast<uintptr_t>(centroids)) & 15) == 0;
     const int qrow = q0 + r < nq ? q0 + r : nq - 1;          // rows beyond nq repeat the last query (never written)
     const float* const qp = queries + (int64_t)qrow * D;
@@ -1102,48 +1107,60 @@ __global__ __launch_bounds__(64 * PR_WAVES) void centroid_probe_kernel(const flo
     // one stage = PR_G k-groups: (1 + PR_T) PR_G 16-byte loads per lane in flight while the previous stage's
     // 4 PR_T PR_G MFMAs run; two waves per SIMD cover the rest of the L2 latency (the first version kept one
     // k-group in flight with one wave per SIMD: 103 us per 2048 queries, all of it load latency)
-    float4 a[PR_G], b[PR_G][PR_T];
+    // two register stages used in turn (no copies between them: a copy at the end of an iteration would wait
+    // for the prefetch it was meant to hide)
+    float4 a0[PR_G], b0[PR_G][PR_T], a1[PR_G], b1[PR_G][PR_T];
+    if (QLDS) {
+        // The query rows come from HBM (read once, never in L2): loaded per stage they put an HBM round trip
+        // in front of every stage's MFMAs (79 us per 2048 queries).  One burst instead: the whole 16 x D tile,
+        // every load in flight at once, zero padded to a multiple of 16 columns.
+        for (int64_t i = tid; i < 16 * (D16 / 4); i += 64 * PR_WAVES) {
+            const int64_t row = i / (D16 / 4), kc = (i - row * (D16 / 4)) * 4;
+            const int qr = q0 + (int)row < nq ? q0 + (int)row : nq - 1;
+            *reinterpret_cast<float4*>(s_qt + row * QS + kc) = ld(queries + (int64_t)qr * D, kc);
+        }
+        __syncthreads();
+    }
     auto load_stage = [&](float4 (&aa)[PR_G], float4 (&bb)[PR_G][PR_T], int64_t k0) {
 #pragma unroll
         for (int g = 0; g < PR_G; ++g) {
-            aa[g] = ld(qp, k0 + 16 * g + 4 * h);
+            if (!QLDS) aa[g] = ld(qp, k0 + 16 * g + 4 * h);  // (beyond D: zeros, which add nothing)
 #pragma unroll
             for (int t = 0; t < PR_T; ++t) bb[g][t] = ld(cp[t], k0 + 16 * g + 4 * h);
         }
     };
-    load_stage(a, b, 0);
-    for (int64_t k0 = 0; k0 < D; k0 += 16 * PR_G) {
-        float4 an[PR_G], bn[PR_G][PR_T];
-        if (k0 + 16 * PR_G < D) load_stage(an, bn, k0 + 16 * PR_G);
-        else {
+    auto compute = [&](float4 (&aa)[PR_G], const float4 (&bb)[PR_G][PR_T], int64_t k0) {
+        if (QLDS) {
 #pragma unroll
             for (int g = 0; g < PR_G; ++g) {
-                an[g] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                for (int t = 0; t < PR_T; ++t) bn[g][t] = make_float4(0.f, 0.f, 0.f, 0.f);
+                const int64_t k = k0 + 16 * g + 4 * h;
+                aa[g] = k < D16 ? *reinterpret_cast<const float4*>(s_qt + r * QS + k) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
 #pragma unroll
         for (int g = 0; g < PR_G; ++g) {
 #pragma unroll
             for (int t = 0; t < PR_T; ++t) {
-                cn[t] = fmaf(b[g][t].x, b[g][t].x, cn[t]); cn[t] = fmaf(b[g][t].y, b[g][t].y, cn[t]);
-                cn[t] = fmaf(b[g][t].z, b[g][t].z, cn[t]); cn[t] = fmaf(b[g][t].w, b[g][t].w, cn[t]);
+                cn[t] = fmaf(bb[g][t].x, bb[g][t].x, cn[t]); cn[t] = fmaf(bb[g][t].y, bb[g][t].y, cn[t]);
+                cn[t] = fmaf(bb[g][t].z, bb[g][t].z, cn[t]); cn[t] = fmaf(bb[g][t].w, bb[g][t].w, cn[t]);
             }
 #pragma unroll
             for (int t = 0; t < PR_T; ++t) {
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g].x, b[g][t].x, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g].y, b[g][t].y, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g].z, b[g][t].z, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g].w, b[g][t].w, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[g].x, bb[g][t].x, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[g].y, bb[g][t].y, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[g].z, bb[g][t].z, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[g].w, bb[g][t].w, acc[t], 0, 0, 0);
             }
         }
-#pragma unroll
-        for (int g = 0; g < PR_G; ++g) {
-            a[g] = an[g];
-#pragma unroll
-            for (int t = 0; t < PR_T; ++t) b[g][t] = bn[g][t];
-        }
+    };
+    constexpr int64_t STAGE = 16 * PR_G;
+    load_stage(a0, b0, 0);
+    for (int64_t k0 = 0; k0 < D; k0 += 2 * STAGE) {
+        load_stage(a1, b1, k0 + STAGE);
+        compute(a0, b0, k0);
+        if (k0 + STAGE >= D) break;
+        load_stage(a0, b0, k0 + 2 * STAGE);
+        compute(a1, b1, k0 + STAGE);
     }
     // ||c||^2 of centroid c0 + 16 t + r: the four h lanes hold its partials
 #pragma unroll
@@ -1207,8 +1224,17 @@ inline int launch_probe(const float* centroids, const float* queries, int64_t D,
                         int32_t* lq_cnt = nullptr, int32_t* lq_list = nullptr, int lq_stride = 0) {
     (void)dist_ws;
     if (nq <= 0) return AURA_OK;
-    hipLaunchKernelGGL(centroid_probe_kernel, dim3((unsigned)((nq + PR_Q - 1) / PR_Q)), dim3(64 * PR_WAVES), 0, s,
-                       centroids, queries, D, nq, nprobe, mask_out, ids_out, lq_cnt, lq_list, lq_stride);
+    const dim3 grid((unsigned)((nq + PR_Q - 1) / PR_Q)), block(64 * PR_WAVES);
+    if (D <= PR_QLDS_MAX_D) {
+        const size_t lds = (size_t)16 * ((D + 15) / 16 * 16 + 4) * sizeof(float);
+        if (ensure_lds_attr(reinterpret_cast<const void*>(centroid_probe_kernel<true>), (int)(16 * (PR_QLDS_MAX_D + 4) * 4)))
+            return AURA_E_LAUNCH;
+        hipLaunchKernelGGL(centroid_probe_kernel<true>, grid, block, lds, s,
+                           centroids, queries, D, nq, nprobe, mask_out, ids_out, lq_cnt, lq_list, lq_stride);
+    } else {
+        hipLaunchKernelGGL(centroid_probe_kernel<false>, grid, block, 0, s,
+                           centroids, queries, D, nq, nprobe, mask_out, ids_out, lq_cnt, lq_list, lq_stride);
+    }
     return hipGetLastError() == hipSuccess ? AURA_OK : AURA_E_LAUNCH;
 }
 

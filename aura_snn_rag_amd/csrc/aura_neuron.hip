@@ -56,7 +56,15 @@ struct AdExModel {
     __device__ __forceinline__ void init(Lane&, int64_t) const {}
     __device__ __forceinline__ float step(Lane& l, float i_t) const {
         float V = l.s0, w = l.s1;
-        float exp_term = Delta_T * expf((V - V_T) / Delta_T);
+        // The reference's torch.exp on CPU is Intel MKL's vmsExp (high-accuracy mode; checked bit for bit against
+        // libtorch_cpu's export over 10^6 arguments, tests/test_oracle_known_answers.py) -- closed source, within
+        // ~0.51 ulp.  OCML's expf (1 ulp) disagrees with it on ~10 % of the arguments, SLEEF's expf_u10 (restated
+        // and checked bit for bit against libtorch's Sleef_expf16_u10 -- but that is not what torch.exp calls) on
+        // 9.5 %; the CORRECTLY ROUNDED float exp on 1.07 %, each by one ulp: the closest a portable
+        // implementation gets.  exp in fp64 rounded once to fp32 is correctly rounded except where the fp64
+        // result sits within 2^-29 of a rounding boundary.  (The loop is HBM-bound; the fp64 polynomial rides
+        // in its shadow.)
+        float exp_term = Delta_T * (float)exp((double)((V - V_T) / Delta_T));
         float dV = (-(V - E_L) + exp_term - R * w + R * i_t) / tau_m;
         V = V + dt * dV;
         float dw = (a * (V - E_L) - w) / tau_w;

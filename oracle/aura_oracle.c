@@ -168,3 +168,30 @@ void oracle_topk(const float* scores, int64_t N, int k, float* out_s, int32_t* o
     }
     free(taken);
 }
+
+/* SLEEF 3.x Sleef_expf{8,16}_u10 (the vector form with fused multiply-adds: range reduction by ln 2 in two
+ * parts, degree-6 polynomial, ldexp in two halves), restated to find out what the reference's torch.exp is:
+ * it equals libtorch_cpu's Sleef_expf16_u10 bit for bit, and torch.exp is NOT it (it is MKL's vmsExp) --
+ * tests/test_oracle_known_answers.py.  fmaf() is libm's correctly rounded fused multiply-add. */
+static inline float oracle_pow2if(int q) { int32_t i = (int32_t)(q + 0x7f) << 23; float f; memcpy(&f, &i, 4); return f; }
+void oracle_sleef_expf_u10(const float* x, float* out, int64_t n) {
+    const float R_LN2f = 1.442695040888963407359924681001892137426645954152985934135449406931f;
+    const float L2Uf = 0.693145751953125f, L2Lf = 1.428606765330187045e-06f;
+    for (int64_t i = 0; i < n; ++i) {
+        const float d = x[i];
+        const int q = (int)rintf(d * R_LN2f);
+        float s = fmaf((float)q, -L2Uf, d);
+        s = fmaf((float)q, -L2Lf, s);
+        float u = 0.000198527617612853646278381f;
+        u = fmaf(u, s, 0.00139304355252534151077271f);
+        u = fmaf(u, s, 0.00833336077630519866943359f);
+        u = fmaf(u, s, 0.0416664853692054748535156f);
+        u = fmaf(u, s, 0.166666671633720397949219f);
+        u = fmaf(u, s, 0.5f);
+        u = 1.0f + fmaf(s * s, u, s);
+        u = u * oracle_pow2if(q >> 1) * oracle_pow2if(q - (q >> 1));
+        if (d < -104.0f) u = 0.0f;
+        if (d > 100.0f) u = INFINITY;
+        out[i] = u;
+    }
+}

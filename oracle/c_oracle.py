@@ -73,3 +73,10 @@ def knn_query(bank, meta, q, now, k):
     out_s = torch.empty(k); out_i = torch.empty(k, dtype=torch.int32)
     lib().oracle_topk(_p(scores), c_int64(N), c_int(k), _p(out_s), _p(out_i))
     return out_s, out_i
+
+
+def sleef_expf_u10(x: torch.Tensor) -> torch.Tensor:
+    """SLEEF's vector expf_u10 restated (see aura_oracle.c)."""
+    x = x.float().contiguous(); out = torch.empty_like(x)
+    lib().oracle_sleef_expf_u10(_p(x), _p(out), c_int64(x.numel()))
+    return out

@@ -55,10 +55,14 @@ def test_izhikevich_btd_bit_exact(dev, B, T, D):
     assert torch.equal(izh.v.cpu(), rv) and torch.equal(izh.u.cpu(), ru)
 
 
-@pytest.mark.parametrize("N,T", [(64, 200), (1000, 64), (77, 33)])
+@pytest.mark.parametrize("N,T", [(64, 200), (1000, 64), (77, 33), (4096, 100)])
 def test_adex_nt(dev, N, T):
-    """AdEx: spike trains identical; V, w agree except where exp() ulp differences are amplified
-    by the model's own exponential upswing (tolerance documented in DESIGN.md)."""
+    """AdEx: spike trains IDENTICAL; V, w within 1e-5 of the reference path on >= 99.5 % of
+    the neurons and within the round-2 bar (1e-4) on >= 99.8 %.  The reference's exp is MKL's closed-source
+    vmsExp; the kernel uses the correctly rounded exp, which differs from it by one ulp on 1.07 % of the
+    arguments (tests/test_oracle_known_answers.py::test_reference_exp_is_mkl_and_correct_rounding_is_closest);
+    such an ulp only shows where the model's own exponential upswing amplifies it: a neuron caught mid-spike at
+    the last step (|V| up to 1e10 there)."""
     from aura_snn_rag_amd.base.neuron import AdExNeuron
     g = torch.Generator().manual_seed(N + T)
     I = 600 * torch.rand(N, T, generator=g)
@@ -67,10 +71,13 @@ def test_adex_nt(dev, N, T):
     p = O.adex_params(a=2.0, b=60.0)
     rs, rV, rw = O.adex_run(I, torch.full((N,), float(p[1])), torch.zeros(N), p)
     assert rs.sum() > 0
-    mism = (s.cpu() != rs).float().mean().item()
-    assert mism <= 1e-4, f"spike mismatch fraction {mism}"
-    close = torch.isclose(ad.V.cpu(), rV, rtol=1e-4, atol=1e-4) & torch.isclose(ad.w.cpu(), rw, rtol=1e-4, atol=1e-3)
-    assert close.float().mean().item() >= 0.98
+    assert torch.equal(s.cpu(), rs), f"spike mismatch fraction {(s.cpu() != rs).float().mean().item()}"
+    V, w = ad.V.cpu(), ad.w.cpu()
+    c5 = torch.isclose(V, rV, rtol=1e-5, atol=1e-5) & torch.isclose(w, rw, rtol=1e-5, atol=1e-5)
+    c4 = torch.isclose(V, rV, rtol=1e-4, atol=1e-4) & torch.isclose(w, rw, rtol=1e-4, atol=1e-3)
+    print(f"\n[adex {N} x {T}] within 1e-5: {c5.float().mean().item():.4f}, within 1e-4: {c4.float().mean().item():.4f}")
+    assert c5.float().mean().item() >= 0.995
+    assert c4.float().mean().item() >= 0.998
 
 
 def test_adex_btd(dev):
