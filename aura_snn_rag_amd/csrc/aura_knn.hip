@@ -441,6 +441,209 @@ __global__ __launch_bounds__(1024) void online_assign_kernel(float* meta, float*
     if (tid < eff_k) counts[tid] = s_counts[tid];
 }
 
+// ---- phase B, pipelined form (D <= 1024: one centroid element per thread) ----
+// The simple form above spends ~2 us per row on three global round trips inside the serial chain: the row's d0
+// line, the winning centroid's row, the acknowledgement of its store.  Here nothing in the chain leaves the CU
+// when a row's decision is clear (the usual case):
+//   * d0[i], x_i and the centroid row of row i's PREDICTED winner (argmin of d0[i], computed by
+//     online_pred_kernel) are loaded three rows ahead into registers; the prediction is right whenever the bound
+//     decides the row, and a predicted row that an update of the last two iterations has overtaken is replaced
+//     by that update's own result, kept in registers (a thread only ever writes element `tid` of a centroid row,
+//     so its own loads see its own stores: single-thread coherence; cross-thread reads happen only in the
+//     re-scoring branch, behind a fence and a barrier);
+//   * wave 0 decides from registers and LDS and publishes (winner, eta) in a two-slot mailbox: ONE barrier per row;
+//   * centroid ids go to a dense array (scattered into the metadata by a parallel launch afterwards).
+struct OnlSlot { float x, cpre; int cid; float d[4]; };
+
+__global__ __launch_bounds__(256) void online_pred_kernel(const float* __restrict__ d0, int eff_k, int64_t n,
+                                                          int32_t* __restrict__ pred) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    float bd = INFINITY;
+    int best = 0x7fffffff;
+    for (int c = lane; c < eff_k; c += 64) {
+        const float d = d0[i * 256 + c];
+        if (d < bd) { bd = d; best = c; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float od = __shfl_xor(bd, off);
+        const int ob = __shfl_xor(best, off);
+        if (od < bd || (od == bd && ob < best)) { bd = od; best = ob; }
+    }
+    if (lane == 0) pred[i] = best == 0x7fffffff ? 0 : best;
+}
+
+__global__ __launch_bounds__(256) void online_cid_scatter_kernel(float* meta, const int64_t* __restrict__ slots,
+                                                                 const int32_t* __restrict__ cid, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) meta[slots[i] * 4 + 2] = (float)cid[i];
+}
+
+__global__ __launch_bounds__(1024) void online_assign_fast_kernel(float* centroids, float* counts, int eff_k,
+                                                                  const float* __restrict__ feats,
+                                                                  const float* __restrict__ d0,
+                                                                  const float* __restrict__ xnorm,
+                                                                  const int32_t* __restrict__ pred,
+                                                                  int32_t* __restrict__ cid_out, int64_t n, int64_t D,
+                                                                  int vec4, float rel) {
+    extern __shared__ __attribute__((aligned(16))) float s_row[];   // [D] (re-scoring only)
+    __shared__ float s_delta[256], s_counts[256], s_fresh[256], s_xn[ONL_CHUNK];
+    __shared__ int s_cand[256], s_pred[ONL_CHUNK];
+    __shared__ int s_pub_best[2], s_pub_ncand[2];
+    __shared__ float s_pub_eta[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool owner = tid < D;                              // this thread owns element `tid` of every centroid row
+    if (tid < 256) {
+        s_delta[tid] = 0.0f;
+        s_counts[tid] = tid < eff_k ? counts[tid] : 0.0f;
+    }
+    for (int64_t i = tid; i < n; i += 1024) { s_pred[i] = pred[i]; s_xn[i] = xnorm[i]; }
+    __syncthreads();
+    auto prefetch = [&](OnlSlot& sl, int64_t row) {
+        if (row >= n) return;
+        const int p = s_pred[row];
+        sl.cid = p;
+        if (owner) {
+            sl.x = feats[row * D + tid];
+            sl.cpre = centroids[(int64_t)p * D + tid];
+        }
+        if (wave == 0) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = lane + 64 * u;
+                sl.d[u] = c < eff_k ? d0[row * 256 + c] : INFINITY;
+            }
+        }
+    };
+    auto commit = [&](int64_t i, int best, float dwin_up) {   // (one lane of wave 0)
+        const float cn = s_counts[best] + 1.0f;
+        s_counts[best] = cn;
+        const float eta = 1.0f / fmaxf(cn, 1.0f);
+        s_delta[best] += 1.0001f * (eta * dwin_up) + 3e-7f * (2.0f * s_xn[i] + dwin_up);
+        cid_out[i] = best;
+        s_pub_best[i & 1] = best;
+        s_pub_eta[i & 1] = eta;
+    };
+    int last1_id = -1, last2_id = -1;                         // centroids written in the previous two iterations ...
+    float last1_v = 0.0f, last2_v = 0.0f;                     // ... and this thread's element of what was written
+    auto step = [&](int64_t i, OnlSlot& sl) {
+        if (wave == 0) {
+            float lo[4], hi[4], dl[4];
+            float hmin = INFINITY;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = lane + 64 * u;
+                const bool valid = c < eff_k;
+                dl[u] = s_delta[c];
+                const float m = dl[u] == 0.0f ? 0.0f : sl.d[u] * rel + dl[u] * 1.0001f;
+                lo[u] = valid ? sl.d[u] - m : INFINITY;
+                hi[u] = valid ? sl.d[u] + m : INFINITY;
+                hmin = fminf(hmin, hi[u]);
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) hmin = fminf(hmin, __shfl_xor(hmin, off));
+            unsigned long long cm[4];
+            int total = 0;
+            bool moved = false;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool cnd = lo[u] <= hmin;
+                cm[u] = __ballot(cnd);
+                total += (int)__popcll(cm[u]);
+                moved = moved || (cnd && dl[u] != 0.0f);
+            }
+            const bool any_moved = __ballot(moved) != 0ull;
+            if (total == 0) {
+                if (lane == 0) { s_pub_ncand[i & 1] = 1; commit(i, 0, 0.0f); }
+            } else if (total == 1) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (lo[u] <= hmin) { s_pub_ncand[i & 1] = 1; commit(i, lane + 64 * u, hi[u]); }
+            } else if (!any_moved) {
+                float bd = INFINITY;
+                int best = 0x7fffffff;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (lo[u] <= hmin && sl.d[u] < bd) { bd = sl.d[u]; best = lane + 64 * u; }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const float od = __shfl_xor(bd, off);
+                    const int ob = __shfl_xor(best, off);
+                    if (od < bd || (od == bd && ob < best)) { bd = od; best = ob; }
+                }
+                if (lane == 0) { s_pub_ncand[i & 1] = 1; commit(i, best, bd); }
+            } else {
+                int base = 0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (lo[u] <= hmin) {
+                        const int p = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(cm[u] >> 32),
+                                                  __builtin_amdgcn_mbcnt_lo((unsigned)cm[u], 0u));
+                        s_cand[p] = lane + 64 * u;
+                    }
+                    base += (int)__popcll(cm[u]);
+                }
+                if (lane == 0) s_pub_ncand[i & 1] = total;
+            }
+        }
+        __syncthreads();
+        const int ncand = s_pub_ncand[i & 1];
+        if (ncand > 1) {                                    // (workgroup-uniform) re-score the candidates
+            if (owner) s_row[tid] = sl.x;
+            __threadfence_block();                          // every thread's centroid stores are done ...
+            __syncthreads();                                // ... before any wave reads whole rows
+            for (int ci = wave; ci < ncand; ci += 16) {
+                const float d = centroid_dist_wave(s_row, centroids + (int64_t)s_cand[ci] * D, D, lane, vec4 != 0);
+                if (lane == 0) s_fresh[ci] = d;
+            }
+            __syncthreads();
+            if (wave == 0) {
+                float bd = INFINITY;
+                int bi = 0x7fffffff;
+                for (int ci = lane; ci < ncand; ci += 64) {
+                    const float d = s_fresh[ci];
+                    if (d < bd) { bd = d; bi = ci; }
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const float od = __shfl_xor(bd, off);
+                    const int ob = __shfl_xor(bi, off);
+                    if (od < bd || (od == bd && ob < bi)) { bd = od; bi = ob; }
+                }
+                if (lane == 0) commit(i, s_cand[bi == 0x7fffffff ? 0 : bi], bd * (1.0f + rel));
+            }
+            __syncthreads();
+        }
+        const int best = s_pub_best[i & 1];
+        const float eta = s_pub_eta[i & 1];
+        const float one_m = 1.0f - eta;
+        if (owner) {
+            float c_old;
+            if (best == last1_id) c_old = last1_v;           // the newest value of that row is still in a register
+            else if (best == last2_id) c_old = last2_v;
+            else if (best == sl.cid) c_old = sl.cpre;        // prefetched behind every older store of this thread
+            else c_old = centroids[(int64_t)best * D + tid]; // prediction missed: one L2 round trip
+            const float c_new = one_m * c_old + eta * sl.x;
+            centroids[(int64_t)best * D + tid] = c_new;
+            last2_v = last1_v; last1_v = c_new;
+        }
+        last2_id = last1_id; last1_id = best;
+        prefetch(sl, i + 3);                                 // (issued behind this iteration's store)
+    };
+    OnlSlot a, b, c;
+    a.cid = b.cid = c.cid = -1;
+    prefetch(a, 0); prefetch(b, 1); prefetch(c, 2);
+    for (int64_t i = 0; i < n; i += 3) {
+        step(i, a);
+        if (i + 1 < n) step(i + 1, b);
+        if (i + 2 < n) step(i + 2, c);
+    }
+    __syncthreads();
+    if (tid < eff_k) counts[tid] = s_counts[tid];
+}
+
 __global__ __launch_bounds__(256) void bank_decay_kernel(float* meta, float factor, int64_t count) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < count) meta[i * 4] *= factor;
@@ -1067,7 +1270,8 @@ constexpr int PR_QLDS_MAX_D = 2048;        // query tile in LDS up to this many 
 constexpr int PR_KSTRIDE = 260;            // floats per key row in LDS (260 % 32 = 4: the four query groups of a
                                            // wave read different banks)
 
-template <bool QLDS>                       // the workgroup's 16 queries staged in LDS once (D <= PR_QLDS_MAX_D)
+template <bool QLDS, bool VEC>             // QLDS: the workgroup's 16 queries staged in LDS once (D <= PR_QLDS_MAX_D);
+                                           // VEC: 16-byte loads (D % 4 == 0, aligned bases)
 __global__ __launch_bounds__(64 * PR_WAVES) void centroid_probe_kernel(const float* __restrict__ centroids,
                                                              const float* __restrict__ queries,
                                                              int64_t D, int nq, int nprobe,
@@ -1083,20 +1287,27 @@ __global__ __launch_bounds__(64 * PR_WAVES) void centroid_probe_kernel(const flo
     const int c0 = wave * (16 * PR_T);
     const int64_t D16 = (D + 15) / 16 * 16;
     const int64_t QS = D16 + 4;                               // row stride: 16 rows x ds_read_b128 hit 64 different banks
-    const bool vec = (D & 3) == 0 && ((reinterpret_cast<uintptr_t>(queries) | reinterpret_cast<uintptr_t>(centroids)) & 15) == 0;
     const int qrow = q0 + r < nq ? q0 + r : nq - 1;          // rows beyond nq repeat the last query (never written)
     const float* const qp = queries + (int64_t)qrow * D;
     const float* cp[PR_T];
 #pragma unroll
     for (int t = 0; t < PR_T; ++t) cp[t] = centroids + (int64_t)(c0 + 16 * t + r) * D;
+    // Branch-free loads: the address is clamped into the row and lanes beyond D are zeroed by a select.  (With
+    // `if (k < D)` around the load hipcc built a diamond per load, each with its own s_waitcnt vmcnt(0): every
+    // load waited for the one before it -- 73-103 us per 2048 queries whatever the pipeline depth.)
     auto ld = [&](const float* base, int64_t k) -> float4 {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (vec) { if (k < D) v = *reinterpret_cast<const float4*>(base + k); }
-        else {
-            if (k + 0 < D) v.x = base[k + 0];
-            if (k + 1 < D) v.y = base[k + 1];
-            if (k + 2 < D) v.z = base[k + 2];
-            if (k + 3 < D) v.w = base[k + 3];
+        float4 v;
+        if (VEC) {
+            const int64_t kk = k < D ? k : D - 4;            // D % 4 == 0, D >= 4
+            v = *reinterpret_cast<const float4*>(base + kk);
+            const bool in = k < D;
+            v.x = in ? v.x : 0.0f; v.y = in ? v.y : 0.0f; v.z = in ? v.z : 0.0f; v.w = in ? v.w : 0.0f;
+        } else {
+            const int64_t l = D - 1;
+            const float x0 = base[k + 0 < D ? k + 0 : l], x1 = base[k + 1 < D ? k + 1 : l];
+            const float x2 = base[k + 2 < D ? k + 2 : l], x3 = base[k + 3 < D ? k + 3 : l];
+            v.x = k + 0 < D ? x0 : 0.0f; v.y = k + 1 < D ? x1 : 0.0f;
+            v.z = k + 2 < D ? x2 : 0.0f; v.w = k + 3 < D ? x3 : 0.0f;
         }
         return v;
     };
@@ -1225,16 +1436,20 @@ inline int launch_probe(const float* centroids, const float* queries, int64_t D,
     (void)dist_ws;
     if (nq <= 0) return AURA_OK;
     const dim3 grid((unsigned)((nq + PR_Q - 1) / PR_Q)), block(64 * PR_WAVES);
+    const bool vec = (D & 3) == 0 && ((reinterpret_cast<uintptr_t>(queries) | reinterpret_cast<uintptr_t>(centroids)) & 15) == 0;
+#define AURA_PROBE(QL, VC, LDS) hipLaunchKernelGGL((centroid_probe_kernel<QL, VC>), grid, block, LDS, s, centroids, queries, D, nq, \
+                                                   nprobe, mask_out, ids_out, lq_cnt, lq_list, lq_stride)
     if (D <= PR_QLDS_MAX_D) {
         const size_t lds = (size_t)16 * ((D + 15) / 16 * 16 + 4) * sizeof(float);
-        if (ensure_lds_attr(reinterpret_cast<const void*>(centroid_probe_kernel<true>), (int)(16 * (PR_QLDS_MAX_D + 4) * 4)))
+        const int lds_max = (int)(16 * (PR_QLDS_MAX_D + 4) * 4);
+        if (ensure_lds_attr(reinterpret_cast<const void*>(centroid_probe_kernel<true, true>), lds_max) ||
+            ensure_lds_attr(reinterpret_cast<const void*>(centroid_probe_kernel<true, false>), lds_max))
             return AURA_E_LAUNCH;
-        hipLaunchKernelGGL(centroid_probe_kernel<true>, grid, block, lds, s,
-                           centroids, queries, D, nq, nprobe, mask_out, ids_out, lq_cnt, lq_list, lq_stride);
+        if (vec) AURA_PROBE(true, true, lds); else AURA_PROBE(true, false, lds);
     } else {
-        hipLaunchKernelGGL(centroid_probe_kernel<false>, grid, block, 0, s,
-                           centroids, queries, D, nq, nprobe, mask_out, ids_out, lq_cnt, lq_list, lq_stride);
+        if (vec) AURA_PROBE(false, true, 0); else AURA_PROBE(false, false, 0);
     }
+#undef AURA_PROBE
     return hipGetLastError() == hipSuccess ? AURA_OK : AURA_E_LAUNCH;
 }
 
@@ -2162,7 +2377,7 @@ int aura_bank_write(float* bank, float* loc, float* meta, float* inv_norm, float
 int64_t aura_bank_write_online_workspace_bytes(int64_t n) {
     if (n < 0) return -1;
     const int64_t ch = n < ONL_CHUNK ? (n > 0 ? n : 1) : ONL_CHUNK;
-    return align_up(ch * 256 * 4, 256) + align_up(ch * 4, 256);
+    return align_up(ch * 256 * 4, 256) + 3 * align_up(ch * 4, 256);
 }
 
 int aura_bank_write_online(float* bank, float* loc, float* meta, float* inv_norm, float* centroids,
@@ -2190,6 +2405,11 @@ int aura_bank_write_online(float* bank, float* loc, float* meta, float* inv_norm
     const int64_t ch = n < ONL_CHUNK ? n : ONL_CHUNK;
     float* const d0 = static_cast<float*>(workspace);
     float* const xnorm = reinterpret_cast<float*>(static_cast<char*>(workspace) + align_up(ch * 256 * 4, 256));
+    int32_t* const pred = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(xnorm) + align_up(ch * 4, 256));
+    int32_t* const cid = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(pred) + align_up(ch * 4, 256));
+    static const bool simple = getenv("AURA_ONLINE_SIMPLE") != nullptr;   // A/B runs: the unpipelined phase B
+    const bool fast = D <= 1024 && !simple;
+    if (fast && ensure_lds_attr(reinterpret_cast<const void*>(online_assign_fast_kernel), 8 * 1024)) return AURA_E_LAUNCH;
     // fp slack of a computed distance against the exact one, both ways: 2 x (chain of D/64 fmaf + 6 butterfly
     // adds + subtraction, square root) x 2^-24, with a factor 2 in hand
     const float rel = 4.0f * ((float)((D + 63) / 64) + 10.0f) * 5.9604645e-8f;
@@ -2199,8 +2419,18 @@ int aura_bank_write_online(float* bank, float* loc, float* meta, float* inv_norm
         hipLaunchKernelGGL(online_dist0_kernel, dim3((unsigned)((nr * groups + 3) / 4)), dim3(256), 0, s,
                            feats + r0 * D, centroids, eff_k, nr, D, vec4, d0, xnorm);
         if ((rc = check_launch())) return rc;
-        hipLaunchKernelGGL(online_assign_kernel, dim3(1), dim3(1024), lds, s, meta, centroids, centroid_counts, eff_k,
-                           feats + r0 * D, slots + r0, d0, xnorm, nr, D, vec4, rel);
+        if (fast) {
+            hipLaunchKernelGGL(online_pred_kernel, dim3((unsigned)((nr + 3) / 4)), dim3(256), 0, s, d0, eff_k, nr, pred);
+            if ((rc = check_launch())) return rc;
+            hipLaunchKernelGGL(online_assign_fast_kernel, dim3(1), dim3(1024), lds, s, centroids, centroid_counts, eff_k,
+                               feats + r0 * D, d0, xnorm, pred, cid, nr, D, vec4, rel);
+            if ((rc = check_launch())) return rc;
+            hipLaunchKernelGGL(online_cid_scatter_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, s, meta,
+                               slots + r0, cid, nr);
+        } else {
+            hipLaunchKernelGGL(online_assign_kernel, dim3(1), dim3(1024), lds, s, meta, centroids, centroid_counts, eff_k,
+                               feats + r0 * D, slots + r0, d0, xnorm, nr, D, vec4, rel);
+        }
         if ((rc = check_launch())) return rc;
     }
     return AURA_OK;

@@ -209,7 +209,7 @@ class ShardedHippocampus:
                 sd = loc.memory_locations.shape[1]
                 sc = self._scratch
                 if sc is None or sc[0].shape[0] < run or sc[0].device != dev:
-                    cap = max(run, int(loc.centroids_update_interval))
+                    cap = max(run, min(int(loc.centroids_update_interval), 4096))
                     sc = self._scratch = (torch.empty(cap, D, device=dev), torch.empty(cap, sd, device=dev),
                                           torch.empty(cap, 4, device=dev), torch.empty(cap, device=dev),
                                           torch.arange(cap, dtype=torch.int64, device=dev))
