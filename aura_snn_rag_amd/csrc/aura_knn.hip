@@ -1156,7 +1156,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void knn_scan_filter_v2(const ScanArg
         for (int e = 0; e < 16; ++e) {
             const int q = qoff + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
             iq[e] = q < a.nq ? a.inv_q[q] : 0.0f;
-            thrf[e] = q < a.nq ? ord_unkey(a.thr[q]) : INFINITY;   // same order as the key compare
+            thrf[e] = q < a.nq ? ord_unkey(a.thr[q]) : __builtin_nanf("");   // same order as the key compare; padding
+                                                                              // queries: NaN ("comb >= NaN" never holds, comb may be +inf)
         }
         unsigned long long pass = 0ull;
 #pragma unroll

@@ -667,7 +667,8 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
                 key[b] = a.thr[q < a.nq ? q : a.nq - 1];
             }
 #pragma unroll
-            for (int b = 0; b < NBc; ++b) thrf[b] = qoff + 16 * b + lr < a.nq ? ord_unkey(key[b]) : INFINITY;
+            for (int b = 0; b < NBc; ++b)                   // padding columns: NaN, "U >= NaN" never holds (U may be +inf)
+                thrf[b] = qoff + 16 * b + lr < a.nq ? ord_unkey(key[b]) : __builtin_nanf("");
         } else {
 #pragma unroll
             for (int b = 0; b < NBc; ++b) thrf[b] = INFINITY;
@@ -916,7 +917,7 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
                     } else {
                         const float up = acc[b][e] * rc[0] + rc[1];
                         uv[b * 4 + e] = up;
-                        bits |= (ok && up >= thrf[b]) ? (1u << (b * 4 + e)) : 0u;   // thrf = +inf: q >= nq
+                        bits |= (ok && up >= thrf[b]) ? (1u << (b * 4 + e)) : 0u;   // thrf = NaN: no query in this column
                     }
                 }
             }

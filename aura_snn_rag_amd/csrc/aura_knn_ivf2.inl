@@ -210,8 +210,12 @@ __global__ __launch_bounds__(256) void ivf2_slots_kernel(const int32_t* __restri
         q = packed >> 4; p = packed & 15;
     }
     slotq[vs] = q;
-    thr[vs] = 0xff800000u;                                  // ord_key(+inf): nothing passes until the threshold
-    eq_slot[vs] = q >= 0 ? eq_q[q] : 0.0f;                  // kernel lowers it; padding columns stay finite
+    // used slot: ord_key(+inf), nothing passes until the threshold kernel lowers it.  Unused slot: the key of a
+    // NaN -- "U >= NaN" is false for EVERY U.  (+inf is not enough: a row stamped in the future of `now` has
+    // U = +inf, passes "+inf >= +inf", and the candidate of query -1 lands in front of the lists: corrupted
+    // counters, then a device fault.  Found by a bank whose seeding and recall clocks disagreed.)
+    thr[vs] = q >= 0 ? 0xff800000u : 0xffc00000u;
+    eq_slot[vs] = q >= 0 ? eq_q[q] : 0.0f;                  // padding columns stay finite
     if (q >= 0) qslot[(int64_t)q * 8 + p] = (int32_t)vs;
 }
 

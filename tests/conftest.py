@@ -27,3 +27,17 @@ def _built_library():
     if not os.path.exists(lib):
         import __graft_entry__ as g
         g.build()
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """One line with the index-exact counts the parity tests recorded (tests/helpers.record_parity)."""
+    try:
+        from tests.helpers import PARITY
+    except Exception:
+        return
+    if PARITY:
+        import json
+        short = {k: f"{v['exact']}/{v['n']}" + (f" (+{v['score_near_ties']} score near-ties)" if v['score_near_ties'] else "")
+                    + (f" ({v['probe_near_ties_excluded']} probe near-ties excluded)" if v['probe_near_ties_excluded'] else "")
+                 for k, v in sorted(PARITY.items())}
+        terminalreporter.write_line("PARITY_COUNTS index-exact queries vs the CPU oracle: " + json.dumps(short))

@@ -1,0 +1,46 @@
+"""Round-3 regressions of the recall kernels."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("nq", [40, 900])
+def test_rows_stamped_in_the_future_score_inf_and_do_not_fault(dev, nq):
+    """Rows whose timestamp lies far in the future of `now` score exp(+huge) = +inf in the reference
+    (hippocampal.py:288-289) and here.  The prefilter used +inf as the "nothing passes" threshold of padding
+    query columns; U = +inf passed it, and the candidate of query -1 corrupted the candidate counters (a device
+    fault in round 3's first sharded test, whose seeding and recall clocks disagreed).  Padding thresholds are NaN
+    now; every path returns the same rows as the all-fp32 kernels: the inf rows first, ties to the lower row."""
+    from aura_snn_rag_amd import ops
+    from aura_snn_rag_amd.core.hippocampal import HippocampalFormation
+    D, N, k = 64, 30000, 9
+    g = torch.Generator().manual_seed(3)
+    centres = torch.randn(150, D, generator=g) * 3
+    feats = centres[torch.randint(0, 150, (N,), generator=g)] + torch.randn(N, D, generator=g)
+    q = (centres[torch.randint(0, 150, (nq,), generator=g)] + torch.randn(nq, D, generator=g)).to(dev).contiguous()
+    hf = HippocampalFormation(feature_dim=D, max_memories=N + 100, n_place_cells=8, n_time_cells=4, n_grid_cells=4,
+                              device="cuda", use_centroid_index=True)
+    hf.bulk_write(feats.to(dev), rebuild=False)
+    hf.rebuild_centroids(perm=torch.randperm(N, generator=g))
+    now = 1.7e9
+    hf.memory_metadata[:, 1] = now
+    hf.memory_metadata[: 2 * N // 3, 1] = now + 9.0e7            # two thirds of the rows: exp(25000) = +inf
+    hf.memory_metadata[5:N:7, 0] = 0.25                           # (inf * strength stays inf)
+    s_m, r_m = ops.knn_search(hf.memory_features, hf._inv_norm, hf.memory_metadata, q, k, now, count=N,
+                              centroids=hf.centroids, nprobe=8, fp32_scan=True)
+    s_p, r_p = hf.recall_batch(q, k=k, now=now)                   # product path (probe masks / inverted lists)
+    assert torch.equal(r_p, r_m) and torch.equal(s_p, s_m)
+    assert bool(torch.isinf(s_p[:, 0]).all())
+    s_e, r_e = hf.recall_batch(q, k=k, now=now, use_candidates=False)
+    s_f, r_f = ops.knn_search(hf.memory_features, hf._inv_norm, hf.memory_metadata, q, k, now, count=N, fp32_scan=True)
+    assert torch.equal(r_e, r_f) and torch.equal(s_e, s_f)
+    # the two-stage kernels themselves (no fallback): they must flag the overflow, never fault
+    ivf = hf._ensure_ivf()
+    s2, r2, ovf = ops.knn_search_ivf2(hf.memory_features, hf._inv_norm, hf.memory_metadata, q, k, now, hf.centroids, 8,
+                                      ivf.sorted_bf16, hf._rho, ivf.sorted_rows, ivf.pad_off, ivf.list_len,
+                                      n_sorted=ivf.n_sorted, lists_flag=ivf.flag)
+    f = int(ovf.item())
+    assert (f & 16) == 0, "a candidate with an invalid row id reached the refine stage"
+    if (f & ~ops.KNN_FLAG_NO_CANDIDATES) == 0:
+        assert torch.equal(r2, r_m) and torch.equal(s2, s_m)

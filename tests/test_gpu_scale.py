@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import aura_oracle as O
-from tests.helpers import topk_equivalent
+from tests.helpers import record_parity, topk_equivalent
 
 pytestmark = pytest.mark.gpu
 
@@ -50,11 +50,13 @@ def test_1m_exact_recall_vs_oracle(bank_1m, dev):
     s0, r0 = ops.knn_search(hf.memory_features, hf._inv_norm, hf.memory_metadata, q, k, now, count=N, fp32_scan=True)
     assert torch.equal(r0, r2) and torch.equal(s0, s2)
     assert bool((r2[:150, 0] == pick.to(torch.int32)).all())
-    sub = torch.cat([torch.arange(0, 6), torch.arange(294, 300)])
+    sub = torch.cat([torch.arange(0, 32), torch.arange(268, 300)])      # 32 planted + 32 random queries
     ri, rs = O.knn_exact_batch(host["bank"], host["meta"][:, 0], host["meta"][:, 1], q[sub].cpu(), k, now)
     exact, n, ok = topk_equivalent(r2[sub], s2[sub], ri, rs)
     print(f"\n[1M x 768 exact recall] index-exact queries vs oracle: {exact}/{n}")
-    assert ok and exact >= n - 1
+    # ok: every row that differs from the oracle's is one whose oracle score ties the oracle's pick within 2e-6
+    record_parity("1Mx768_exact_recall_k32", exact, n, score_near_ties=n - exact if ok else 0)
+    assert ok, "a row differs from the oracle's beyond an fp32 near-tie"
     sc = s2.cpu()
     assert bool((sc[:, :-1] >= sc[:, 1:]).all()) and bool((r2 >= 0).all()) and bool((r2 < N).all())
 
@@ -62,7 +64,7 @@ def test_1m_exact_recall_vs_oracle(bank_1m, dev):
 def test_1m_centroid_index_paths_vs_oracle(bank_1m, dev):
     """Centroid-index recall at 1M x 768: inverted lists on the two-stage scan (the product's path) ==
     fp32 inverted lists == masked two-stage scan == masked fp32 scan, bit for bit on 300 queries; the
-    oracle's candidate path on 8 of them (queries whose 8th / 9th nearest centroids are an fp32
+    oracle's candidate path on 64 of them (queries whose 8th / 9th nearest centroids are an fp32
     near-tie are compared against the masked fp32 scan only: the probe set itself is ambiguous)."""
     from aura_snn_rag_amd import ops
     hf, q, pick, now, host = bank_1m
@@ -85,7 +87,7 @@ def test_1m_centroid_index_paths_vs_oracle(bank_1m, dev):
     ob = O.OracleBank(1, 768)
     ob.M = N; ob.features = host["bank"]; ob.metadata = host["meta"]; ob.centroids = host["cent"]
     ob.index_ready = True; ob.count = N
-    sub = [0, 1, 2, 3, 296, 297, 298, 299]
+    sub = list(range(0, 32)) + list(range(268, 300))                  # 32 planted + 32 random queries
     exact = ties = 0
     for j in sub:
         qq = q[j].cpu()
@@ -99,7 +101,10 @@ def test_1m_centroid_index_paths_vs_oracle(bank_1m, dev):
         exact += e
     print(f"\n[1M x 768 centroid-index recall] index-exact queries vs oracle: {exact}/{len(sub) - ties} "
           f"({ties} probe near-ties skipped)")
-    assert exact >= len(sub) - ties - 1
+    # (every compared query passed `ok` above: rows equal except at score near-ties of the oracle's own scores)
+    record_parity("1Mx768_centroid_index_recall_k32", exact, len(sub) - ties, score_near_ties=len(sub) - ties - exact,
+                  probe_near_ties=ties)
+    assert len(sub) - ties >= 48, "too many probe near-ties to call this a parity check"
 
 
 def test_config4_shard_shape_vs_oracle(dev):
@@ -120,11 +125,12 @@ def test_config4_shard_shape_vs_oracle(dev):
     assert torch.equal(i0, i1) and torch.equal(s0, s1)
     assert bool((i1 >= base).all()) and bool((i1 < base + N).all())
     assert bool((i1[: nq // 2, 0].cpu() == (pick + base).to(torch.int32)).all())
-    sub = torch.cat([torch.arange(0, 8), torch.arange(nq - 8, nq)])
+    sub = torch.cat([torch.arange(0, 32), torch.arange(nq - 32, nq)])
     ri, rs = O.knn_exact_batch(bank, meta[:, 0], meta[:, 1], q[sub], k, 1.7e9)
     exact, n, ok = topk_equivalent(i1[sub] - base, s1[sub], ri, rs)
     print(f"\n[config-4 shard 125000 x 768, 2048 queries, idx_base {base}] index-exact queries vs oracle: {exact}/{n}")
-    assert ok and exact >= n - 1
+    record_parity("config4_shard_125000x768_k32", exact, n, score_near_ties=n - exact if ok else 0)
+    assert ok
 
 
 # ----------------------------------------------------------------------------------------------

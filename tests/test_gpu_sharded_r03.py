@@ -4,6 +4,7 @@ permutation broadcast and the bound exchange all run through RCCL on the one-GPU
 exchange itself (staged inverted-list recall == the unstaged one, bit for bit)."""
 import os
 import socket
+import sys
 
 import pytest
 import torch
@@ -38,19 +39,31 @@ def _rccl_worker(rank, port, out):
               use_centroid_index=True, overflow="fifo")
     now = 1.7e9
     res = {}
+    trace = os.environ.get("AURA_TEST_TRACE") is not None
+
+    def mark(what):                                                 # AURA_TEST_TRACE: localise a device fault
+        if trace:
+            torch.cuda.synchronize()
+            print(f"[rccl-test] ok: {what}", file=sys.stderr, flush=True)
     for name, force in (("plain", False), ("rccl", True)):
         local = HippocampalFormation(**kw)
         local.centroids_update_interval = 10 ** 9
         sh = ShardedHippocampus(local, M, now_fn=lambda: now, force_collectives=force)
-        sh.bulk_write(feats[:20000].to(dev))
+        sh.bulk_write(feats[:20000].to(dev)); mark(f"{name} bulk_write")
         for i in range(20000, 30000, 4000):
             sh.write([f"m{j}" for j in range(i, min(i + 4000, 30000))], feats[i:i + 4000])
+        mark(f"{name} writes")
         sh.rebuild_centroids(perm=None if force else perm)          # forced: rank 0's draw is BROADCAST ...
+        mark(f"{name} rebuild")
         if force:
             sh.rebuild_centroids(perm=perm)                          # ... then the same perm as the plain run
         sh.write([f"x{j}" for j in range(400)], extra)               # replicated online centroid update
+        mark(f"{name} online write")
+        local.memory_metadata[:, 1] = now                            # bulk_write stamps the wall clock: one clock for both runs
         s_c, r_c = sh.recall_batch(q.to(dev), k=9, now=now, all_gather_queries=True)
+        mark(f"{name} candidate recall")
         s_e, r_e = sh.recall_batch(q.to(dev), k=9, now=now, use_candidates=False)
+        mark(f"{name} exact recall")
         res[name] = dict(s_c=s_c.cpu(), r_c=r_c.cpu(), s_e=s_e.cpu(), r_e=r_e.cpu(), cent=local.centroids.cpu(),
                          counts=local.centroid_counts.cpu(), meta=local.memory_metadata[:, 2].cpu(),
                          exchanges=sh.exchanges, agreed=sh._exch_ok)
@@ -93,7 +106,9 @@ def test_staged_inverted_list_recall_equals_unstaged(dev):
     kth = s0[:, -1].clone()
     kth[r0[:, -1] < 0] = -3.0e38                                  # fewer than k candidates: no bound from outside
     counts = {}
-    for name, make in (("own", lambda b: torch.maximum(b[:, 0], b[:, 1])),
+    # (column 1, the k2-th largest bound, is only valid as the MINIMUM over `parts` disjoint shards: one bank alone
+    #  may use column 0 only)
+    for name, make in (("own", lambda b: b[:, 0]),
                        ("tight", lambda b: torch.maximum(b[:, 0], kth - 1e-4)),
                        ("none", lambda b: torch.full_like(b[:, 0], -3.0e38))):
         calls = []
