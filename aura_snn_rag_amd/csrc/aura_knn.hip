@@ -1267,7 +1267,8 @@ constexpr int PR_Q = 16;                   // queries per workgroup
 constexpr int PR_WAVES = 8;                // waves per workgroup: wave w owns centroids [32 w, 32 w + 32)
 constexpr int PR_T = 256 / PR_WAVES / 16;  // 16 x 16 output tiles per wave
 constexpr int PR_G = 4;                    // k-groups (16 k each) per software-pipeline stage
-constexpr int PR_QLDS_MAX_D = 2048;        // query tile in LDS up to this many columns (16 x 2052 x 4 B = 128 KiB)
+constexpr int PR_QLDS_MAX_D = 1024;        // query tile in LDS up to this many columns (16 x 1028 x 4 B = 64 KiB, beside
+                                           // 8 x 8 KiB of centroid stages and 16 KiB of keys)
 constexpr int PR_KSTRIDE = 260;            // floats per key row in LDS (260 % 32 = 4: the four query groups of a
                                            // wave read different banks)
 
@@ -1296,22 +1297,31 @@ __global__ __launch_bounds__(64 * PR_WAVES) void centroid_probe_kernel(const flo
     // Branch-free loads: the address is clamped into the row and lanes beyond D are zeroed by a select.  (With
     // `if (k < D)` around the load hipcc built a diamond per load, each with its own s_waitcnt vmcnt(0): every
     // load waited for the one before it -- 73-103 us per 2048 queries whatever the pipeline depth.)
-    auto ld = [&](const float* base, int64_t k) -> float4 {
+    // (the zeroing is a separate step so that a prefetch can leave it to the point of use: applied at load time
+    //  the select waits for the load it belongs to, and the prefetch is no prefetch)
+    auto ld_raw = [&](const float* base, int64_t k) -> float4 {
         float4 v;
         if (VEC) {
             const int64_t kk = k < D ? k : D - 4;            // D % 4 == 0, D >= 4
             v = *reinterpret_cast<const float4*>(base + kk);
-            const bool in = k < D;
-            v.x = in ? v.x : 0.0f; v.y = in ? v.y : 0.0f; v.z = in ? v.z : 0.0f; v.w = in ? v.w : 0.0f;
         } else {
             const int64_t l = D - 1;
-            const float x0 = base[k + 0 < D ? k + 0 : l], x1 = base[k + 1 < D ? k + 1 : l];
-            const float x2 = base[k + 2 < D ? k + 2 : l], x3 = base[k + 3 < D ? k + 3 : l];
-            v.x = k + 0 < D ? x0 : 0.0f; v.y = k + 1 < D ? x1 : 0.0f;
-            v.z = k + 2 < D ? x2 : 0.0f; v.w = k + 3 < D ? x3 : 0.0f;
+            v.x = base[k + 0 < D ? k + 0 : l]; v.y = base[k + 1 < D ? k + 1 : l];
+            v.z = base[k + 2 < D ? k + 2 : l]; v.w = base[k + 3 < D ? k + 3 : l];
         }
         return v;
     };
+    auto ld_mask = [&](float4 v, int64_t k) -> float4 {
+        if (VEC) {
+            const bool in = k < D;
+            v.x = in ? v.x : 0.0f; v.y = in ? v.y : 0.0f; v.z = in ? v.z : 0.0f; v.w = in ? v.w : 0.0f;
+        } else {
+            v.x = k + 0 < D ? v.x : 0.0f; v.y = k + 1 < D ? v.y : 0.0f;
+            v.z = k + 2 < D ? v.z : 0.0f; v.w = k + 3 < D ? v.w : 0.0f;
+        }
+        return v;
+    };
+    auto ld = [&](const float* base, int64_t k) -> float4 { return ld_mask(ld_raw(base, k), k); };
     f32x4v_t acc[PR_T];
     float cn[PR_T];
 #pragma unroll
@@ -1319,6 +1329,54 @@ __global__ __launch_bounds__(64 * PR_WAVES) void centroid_probe_kernel(const flo
     // one stage = PR_G k-groups: (1 + PR_T) PR_G 16-byte loads per lane in flight while the previous stage's
     // 4 PR_T PR_G MFMAs run; two waves per SIMD cover the rest of the L2 latency (the first version kept one
     // k-group in flight with one wave per SIMD: 103 us per 2048 queries, all of it load latency)
+    constexpr int64_t STAGE = 16 * PR_G;
+    if constexpr (QLDS) {
+        // Centroid rows through a wave-private LDS stage.  Loaded straight into the MFMA layout, lane (r, h) reads
+        // 16 bytes of row r: neighbouring lanes sit 3 KB apart, 64 tag look-ups per load instruction (46 us per
+        // 2048 queries, load-issue bound).  Instead a lane loads CONSECUTIVE memory -- 16 lanes cover 256 bytes
+        // of one row, an instruction 4 rows -- the wave writes its 32 rows x 64 k to LDS (16-byte chunk j of row
+        // w at position j ^ (w & 15): the writes and the MFMA-layout reads below are both conflict-free) and
+        // reads its operands back in the MFMA layout.  The stage is private to the wave: no barrier, the LDS
+        // pipe keeps a wave's accesses in order.  The next stage's global loads fly during the MFMAs.
+        float* const s_b = s_qt + 16 * QS + wave * (32 * 64);
+        const int lrow = lane >> 4, lc = lane & 15;          // loader: row lrow + 4 m of the wave's 32, chunk lc
+        float4 nb[8];
+        auto load_b = [&](int64_t k0) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+                nb[m] = ld_raw(centroids + (int64_t)(c0 + lrow + 4 * m) * D, k0 + 4 * lc);
+        };
+        auto store_b = [&](int64_t k0) {                     // (columns beyond D are zeroed here, see ld_mask)
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const int w = lrow + 4 * m;
+                *reinterpret_cast<float4*>(s_b + w * 64 + 4 * (lc ^ (w & 15))) = ld_mask(nb[m], k0 + 4 * lc);
+            }
+        };
+        load_b(0);
+        for (int64_t k0 = 0; k0 < D; k0 += STAGE) {
+            store_b(k0);
+            load_b(k0 + STAGE);                              // unconditional (beyond D the address is clamped and the
+                                                             // data never used): a branch here costs register copies
+                                                             // that wait for the loads they were meant to overlap
+#pragma unroll
+            for (int g = 0; g < PR_G; ++g) {
+                const int64_t k = k0 + 16 * g + 4 * h;
+                const float4 av = k < D16 ? *reinterpret_cast<const float4*>(s_qt + r * QS + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int t = 0; t < PR_T; ++t) {
+                    const int w = 16 * t + r;
+                    const float4 bv = *reinterpret_cast<const float4*>(s_b + w * 64 + 4 * ((4 * g + h) ^ (w & 15)));
+                    cn[t] = fmaf(bv.x, bv.x, cn[t]); cn[t] = fmaf(bv.y, bv.y, cn[t]);
+                    cn[t] = fmaf(bv.z, bv.z, cn[t]); cn[t] = fmaf(bv.w, bv.w, cn[t]);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc[t], 0, 0, 0);
+                }
+            }
+        }
+    } else {
     // two register stages used in turn (no copies between them: a copy at the end of an iteration would wait
     // for the prefetch it was meant to hide)
     float4 a0[PR_G], b0[PR_G][PR_T], a1[PR_G], b1[PR_G][PR_T];
@@ -1365,7 +1423,6 @@ __global__ __launch_bounds__(64 * PR_WAVES) void centroid_probe_kernel(const flo
             }
         }
     };
-    constexpr int64_t STAGE = 16 * PR_G;
     load_stage(a0, b0, 0);
     for (int64_t k0 = 0; k0 < D; k0 += 2 * STAGE) {
         load_stage(a1, b1, k0 + STAGE);
@@ -1373,6 +1430,7 @@ __global__ __launch_bounds__(64 * PR_WAVES) void centroid_probe_kernel(const flo
         if (k0 + STAGE >= D) break;
         load_stage(a0, b0, k0 + 2 * STAGE);
         compute(a1, b1, k0 + STAGE);
+    }
     }
     // ||c||^2 of centroid c0 + 16 t + r: the four h lanes hold its partials
 #pragma unroll
@@ -1441,8 +1499,8 @@ inline int launch_probe(const float* centroids, const float* queries, int64_t D,
 #define AURA_PROBE(QL, VC, LDS) hipLaunchKernelGGL((centroid_probe_kernel<QL, VC>), grid, block, LDS, s, centroids, queries, D, nq, \
                                                    nprobe, mask_out, ids_out, lq_cnt, lq_list, lq_stride)
     if (D <= PR_QLDS_MAX_D) {
-        const size_t lds = (size_t)16 * ((D + 15) / 16 * 16 + 4) * sizeof(float);
-        const int lds_max = (int)(16 * (PR_QLDS_MAX_D + 4) * 4);
+        const size_t lds = ((size_t)16 * ((D + 15) / 16 * 16 + 4) + (size_t)PR_WAVES * 32 * 64) * sizeof(float);
+        const int lds_max = (int)((16 * (PR_QLDS_MAX_D + 4) + PR_WAVES * 32 * 64) * 4);
         if (ensure_lds_attr(reinterpret_cast<const void*>(centroid_probe_kernel<true, true>), lds_max) ||
             ensure_lds_attr(reinterpret_cast<const void*>(centroid_probe_kernel<true, false>), lds_max))
             return AURA_E_LAUNCH;
