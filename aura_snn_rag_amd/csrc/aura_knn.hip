@@ -1329,6 +1329,17 @@ __global__ __launch_bounds__(64 * PR_WAVES) void centroid_probe_kernel(const flo
     // one stage = PR_G k-groups: (1 + PR_T) PR_G 16-byte loads per lane in flight while the previous stage's
     // 4 PR_T PR_G MFMAs run; two waves per SIMD cover the rest of the L2 latency (the first version kept one
     // k-group in flight with one wave per SIMD: 103 us per 2048 queries, all of it load latency)
+    if (QLDS) {
+        // The query rows come from HBM (read once, never in L2): loaded per stage they put an HBM round trip
+        // in front of every stage's MFMAs (79 us per 2048 queries).  One burst instead: the whole 16 x D tile,
+        // every load in flight at once, zero padded to a multiple of 16 columns.
+        for (int64_t i = tid; i < 16 * (D16 / 4); i += 64 * PR_WAVES) {
+            const int64_t row = i / (D16 / 4), kc = (i - row * (D16 / 4)) * 4;
+            const int qr = q0 + (int)row < nq ? q0 + (int)row : nq - 1;
+            *reinterpret_cast<float4*>(s_qt + row * QS + kc) = ld(queries + (int64_t)qr * D, kc);
+        }
+        __syncthreads();
+    }
     constexpr int64_t STAGE = 16 * PR_G;
     if constexpr (QLDS) {
         // Centroid rows through a wave-private LDS stage.  Loaded straight into the MFMA layout, lane (r, h) reads
@@ -1380,17 +1391,6 @@ __global__ __launch_bounds__(64 * PR_WAVES) void centroid_probe_kernel(const flo
     // two register stages used in turn (no copies between them: a copy at the end of an iteration would wait
     // for the prefetch it was meant to hide)
     float4 a0[PR_G], b0[PR_G][PR_T], a1[PR_G], b1[PR_G][PR_T];
-    if (QLDS) {
-        // The query rows come from HBM (read once, never in L2): loaded per stage they put an HBM round trip
-        // in front of every stage's MFMAs (79 us per 2048 queries).  One burst instead: the whole 16 x D tile,
-        // every load in flight at once, zero padded to a multiple of 16 columns.
-        for (int64_t i = tid; i < 16 * (D16 / 4); i += 64 * PR_WAVES) {
-            const int64_t row = i / (D16 / 4), kc = (i - row * (D16 / 4)) * 4;
-            const int qr = q0 + (int)row < nq ? q0 + (int)row : nq - 1;
-            *reinterpret_cast<float4*>(s_qt + row * QS + kc) = ld(queries + (int64_t)qr * D, kc);
-        }
-        __syncthreads();
-    }
     auto load_stage = [&](float4 (&aa)[PR_G], float4 (&bb)[PR_G][PR_T], int64_t k0) {
 #pragma unroll
         for (int g = 0; g < PR_G; ++g) {

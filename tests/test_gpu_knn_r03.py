@@ -44,3 +44,31 @@ def test_rows_stamped_in_the_future_score_inf_and_do_not_fault(dev, nq):
     assert (f & 16) == 0, "a candidate with an invalid row id reached the refine stage"
     if (f & ~ops.KNN_FLAG_NO_CANDIDATES) == 0:
         assert torch.equal(r2, r_m) and torch.equal(s2, s_m)
+
+
+@pytest.mark.parametrize("D,nq,kc", [(32, 1, 16), (32, 37, 16), (8, 5, 256), (64, 900, 200), (96, 16, 256), (100, 33, 256),
+                                     (50, 7, 40), (768, 300, 256), (1024, 20, 256), (1280, 9, 256)])
+def test_centroid_probe_ids_against_float64(dev, D, nq, kc):
+    """aura_centroid_probe (fp32 matrix cores: key = ||c||^2 - 2 q.c; centroid rows through the LDS transposer for
+    D <= 1024, register path above, scalar loads for D % 4 != 0) against the fp64 distances over ALL 256 table
+    rows -- the zero rows beyond centroids_k included, as hippocampal.py:261-262 ranks them too.  A position may
+    differ only where the fp64 distances of the two rows agree to 1e-6 relative (an fp32 near-tie)."""
+    from aura_snn_rag_amd import ops
+    g = torch.Generator().manual_seed(D * 1000 + nq)
+    cent = torch.zeros(256, D)
+    cent[:kc] = torch.randn(kc, D, generator=g) * 0.7
+    q = torch.randn(nq, D, generator=g) * (0.2 + 2 * torch.rand(nq, 1, generator=g))
+    ids = ops.centroid_probe(q.to(dev).contiguous(), cent.to(dev).contiguous(), 8).cpu().long()
+    d = torch.cdist(q.double(), cent.double())
+    ref = torch.topk(d, 8, dim=1, largest=False, sorted=True).indices
+    # ties between the identical zero rows go to the lower row in both (topk is not stable: compare distances)
+    bad = 0
+    for i in range(nq):
+        for p in range(8):
+            if ids[i, p] != ref[i, p]:
+                a, b = float(d[i, ids[i, p]]), float(d[i, ref[i, p]])
+                if abs(a - b) > 1e-6 * max(abs(b), 1e-30):
+                    bad += 1
+    assert bad == 0, f"{bad} probe positions differ beyond an fp32 near-tie"
+    assert bool((ids >= 0).all()) and bool((ids < 256).all())
+    assert all(len(set(r.tolist())) == 8 for r in ids)
