@@ -1364,12 +1364,20 @@ __global__ __launch_bounds__(64 * PR_WAVES) void centroid_probe_kernel(const flo
                 *reinterpret_cast<float4*>(s_b + w * 64 + 4 * (lc ^ (w & 15))) = ld_mask(nb[m], k0 + 4 * lc);
             }
         };
-        load_b(0);
-        for (int64_t k0 = 0; k0 < D; k0 += STAGE) {
+        // Every workgroup walks k in step, and a 64-column slab of the table (256 rows, 3 KB apart) sits on a
+        // few L2 channels: wave w starts its walk at stage w and wraps around, so that the eight waves of a
+        // workgroup -- of every workgroup -- pull from eight different slabs at any time.  (The k order of a
+        // (query, centroid) dot product then depends on the centroid's wave, i.e. on the centroid alone.)
+        const int64_t nst = (D + STAGE - 1) / STAGE;
+        const int64_t st0 = wave % nst;
+        auto stage_k = [&](int64_t it) { const int64_t s_ = st0 + it; return (s_ < nst ? s_ : s_ - nst) * STAGE; };
+        load_b(stage_k(0));
+        for (int64_t it = 0; it < nst; ++it) {
+            const int64_t k0 = stage_k(it);
             store_b(k0);
-            load_b(k0 + STAGE);                              // unconditional (beyond D the address is clamped and the
-                                                             // data never used): a branch here costs register copies
-                                                             // that wait for the loads they were meant to overlap
+            load_b(stage_k(it + 1 < nst ? it + 1 : it));     // unconditional (the last one reloads its own stage, never
+                                                             // used): a branch here costs register copies that wait
+                                                             // for the loads they were meant to overlap
 #pragma unroll
             for (int g = 0; g < PR_G; ++g) {
                 const int64_t k = k0 + 16 * g + 4 * h;
