@@ -1371,13 +1371,27 @@ __global__ __launch_bounds__(64 * PR_WAVES) void centroid_probe_kernel(const flo
         const int64_t nst = (D + STAGE - 1) / STAGE;
         const int64_t st0 = wave % nst;
         auto stage_k = [&](int64_t it) { const int64_t s_ = st0 + it; return (s_ < nst ? s_ : s_ - nst) * STAGE; };
+        float tch = 0.0f;
         load_b(stage_k(0));
+#ifdef AURA_PR_EXP_NOMAIN                                    // timing experiments only (tools/build_variant.sh)
+        for (int64_t it = 0; it < 1; ++it) {
+#else
         for (int64_t it = 0; it < nst; ++it) {
+#endif
             const int64_t k0 = stage_k(it);
             store_b(k0);
+            asm volatile("" ::"v"(tch));                     // (the touch below is long done: store_b waited for all loads)
             load_b(stage_k(it + 1 < nst ? it + 1 : it));     // unconditional (the last one reloads its own stage, never
                                                              // used): a branch here costs register copies that wait
                                                              // for the loads they were meant to overlap
+            {
+                // A stage's lines are new to this XCD's L2 when the first workgroup asks for them: ~1.7 us per stage
+                // with one stage of look-ahead (measured: the whole kernel takes as long for 256 queries as for
+                // 2048).  One dword per 128-byte line of the stage three ahead starts the fill early: 64 lanes = 32
+                // rows x 2 lines, one instruction, no register kept.
+                const int64_t kt = stage_k(it + 3 < nst ? it + 3 : nst - 1) + (lane & 1) * 32;
+                tch = centroids[(int64_t)(c0 + (lane >> 1)) * D + (kt < D ? kt : D - 1)];
+            }
 #pragma unroll
             for (int g = 0; g < PR_G; ++g) {
                 const int64_t k = k0 + 16 * g + 4 * h;
@@ -1454,32 +1468,46 @@ __global__ __launch_bounds__(64 * PR_WAVES) void centroid_probe_kernel(const flo
             s_key[(4 * h + e) * PR_KSTRIDE + c0 + 16 * t + r] = fmaf(-2.0f, acc[t][e], cn[t]);
     __syncthreads();
     if (wave >= PR_Q / 4) return;
+#ifdef AURA_PR_EXP_NOSELECT
+    nprobe = 1;
+#endif
 
     // ---- selection: 16 lanes per query (query 4 wave + h of the workgroup), lane r holds centroids r + 16 m ----
     const int ql = 4 * wave + h;
     const int q = q0 + ql;
-    float kv[16];
+    // keys as ordered uint32 (smaller float <=> smaller key); 16-lane all-reduce by DPP row rotations: the first
+    // version's shuffles (ds_bpermute) cost 1 us per round, 8 us of a 42 us kernel
+    uint32_t kv[16];
 #pragma unroll
-    for (int m = 0; m < 16; ++m) kv[m] = s_key[ql * PR_KSTRIDE + r + 16 * m];
+    for (int m = 0; m < 16; ++m) kv[m] = ord_key(s_key[ql * PR_KSTRIDE + r + 16 * m]);
+    auto row_min = [](uint32_t v) -> uint32_t {              // min over the lane's row of 16, result in every lane
+        uint32_t o;
+        o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false); v = o < v ? o : v;   // row_ror:8
+        o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xf, 0xf, false); v = o < v ? o : v;   // row_ror:4
+        o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x122, 0xf, 0xf, false); v = o < v ? o : v;   // row_ror:2
+        o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x121, 0xf, 0xf, false); v = o < v ? o : v;   // row_ror:1
+        return v;
+    };
     uint32_t alive = 0xffffu;
     uint32_t mword = 0u;                                     // lane r < 8: word r of the query's 256-bit mask
     int my_id = -1;                                          // lane r < 8: the r-th nearest centroid
     for (int p = 0; p < nprobe; ++p) {
-        float bv = INFINITY;
-        int bi = 0x7fff;
+        uint32_t km = 0xffffffffu;
 #pragma unroll
         for (int m = 0; m < 16; ++m) {
-            const bool take = ((alive >> m) & 1u) && (bi == 0x7fff || kv[m] < bv);
-            bv = take ? kv[m] : bv;
-            bi = take ? r + 16 * m : bi;
+            const uint32_t v = ((alive >> m) & 1u) ? kv[m] : 0xffffffffu;
+            km = v < km ? v : km;
         }
+        km = row_min(km);
+        uint32_t bi_u = 0xffffffffu;                         // lowest centroid among the alive entries that hold km
 #pragma unroll
-        for (int off = 1; off < 16; off <<= 1) {
-            const float ov = __shfl_xor(bv, off);
-            const int oi = __shfl_xor(bi, off);
-            if (oi != 0x7fff && (bi == 0x7fff || ov < bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
+        for (int m = 0; m < 16; ++m) {
+            const uint32_t c = (((alive >> m) & 1u) && kv[m] == km) ? (uint32_t)(r + 16 * m) : 0xffffffffu;
+            bi_u = c < bi_u ? c : bi_u;
         }
-        if (bi == 0x7fff) break;                             // nothing left (nprobe > 256 never happens; NaN rows)
+        bi_u = row_min(bi_u);
+        if (bi_u == 0xffffffffu) break;                      // nothing left (all 256 taken)
+        const int bi = (int)bi_u;
         if ((bi & 15) == r) alive &= ~(1u << (bi >> 4));
         if ((bi >> 5) == r) mword |= 1u << (bi & 31);
         if (p == r) my_id = bi;
