@@ -36,7 +36,7 @@ import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 MFMA_F32_PEAK_TF = 157.3    # fp32 matrix peak (v_mfma_f32_32x32x2_f32), dense
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_per_dispatch.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_per_dispatch.json")
 KERNEL_OF_KIND = {0: "knn_scan_filter_v2<true, true>",
                   1: "coarse_scan_kernel<24, 1, false, false, false, 4>",
                   2: "coarse_scan_kernel<24, 1, true, false, false, 8>",
@@ -119,7 +119,7 @@ def profiled(lib, fn, iters, warm=3):
 
 
 def pmc_traffic(kernel, config_key):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/r02_*; PMC and
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/r03_*; PMC and
     timing runs are never mixed).  FETCH_SIZE counts half of a wide streaming read on gfx950
     (MI355X_MICROARCH.md): 2 * FETCH_SIZE + WRITE_SIZE, both in KiB."""
     try:
@@ -131,7 +131,32 @@ def pmc_traffic(kernel, config_key):
     return None
 
 
-def hbm_roofline(kind, kms, launches_per_step, rows, D, nq_launch, config_key):
+def ivf_issued_flop(hf, q, D):
+    """bf16 MFMA FLOP one inverted-list filter launch ISSUES for the batch `q`: per (list, block of <= 256 probing
+    queries) every 16-row tile of the list is multiplied against the 16-query column blocks that hold a query
+    (a wave owns 32 query slots and runs ceil(its queries / 16) column blocks; coarse_scan_kernel), k padded to a
+    multiple of 32.  Also returns the USEFUL FLOP (list rows x probing queries x 2 D)."""
+    ids = hf.probe(q)
+    ivf = hf._ivf
+    if ids is None or ivf is None or not ivf.valid:
+        return None, None
+    cnt = torch.bincount(ids.flatten().long().clamp_(0, 255), minlength=256).cpu().tolist()
+    lens = ivf.list_len.cpu().tolist()
+    kpad = (D + 31) // 32 * 32
+    issued = useful = 0
+    for c in range(256):
+        tiles = (lens[c] + 15) // 16
+        left = cnt[c]
+        useful += 2 * D * lens[c] * cnt[c]
+        while left > 0:
+            nb = min(left, 256)
+            cols = sum(16 * ((min(max(nb - 32 * w, 0), 32) + 15) // 16) for w in range(8))
+            issued += 2 * kpad * 16 * tiles * cols
+            left -= nb
+    return float(issued), float(useful)
+
+
+def hbm_roofline(kind, kms, launches_per_step, rows, D, nq_launch, config_key, issued_flop=None, useful_flop=None):
     """Roofline of the dominant (prefilter) launch.  Algorithmic bytes: every row once -- 2 D (bf16 shadow)
     or 4 D (fp32 rows) + 16 B of row constants."""
     if kms <= 0:
@@ -146,15 +171,24 @@ def hbm_roofline(kind, kms, launches_per_step, rows, D, nq_launch, config_key):
     esz = 4 if kind == 1 else 2
     nbytes = rows * (D * esz + 16)
     gbs = nbytes / (kms * 1e-3) / 1e9
-    tf = 2.0 * nq_launch * rows * D / (kms * 1e-3) / 1e12
-    return {"bound": "hbm", "kernel": KERNEL_OF_KIND[kind] + " (rows streamed once by global_load_lds, "
-            "v_mfma_f32_16x16x32_bf16 against register-resident query fragments)",
-            "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-            "avg_kernel_ms": kms, "launches_per_step": launches_per_step, "rows_per_launch": rows,
-            "queries_per_launch": nq_launch, "algorithmic_bytes_per_launch": nbytes,
-            "traffic": pmc_traffic(KERNEL_OF_KIND[kind], config_key),
-            "traffic_source": "profiles/r02_pmc_per_dispatch.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)",
-            "bf16_tflops_at_kernel_incl_padding": tf}
+    if issued_flop is None and kind in (1, 2):
+        # full scan: every 256-query block multiplies every row (padded query columns and k included)
+        issued_flop = 2.0 * ((nq_launch + 255) // 256 * 256) * rows * ((D + 31) // 32 * 32)
+        useful_flop = 2.0 * nq_launch * rows * D
+    out = {"bound": "hbm", "kernel": KERNEL_OF_KIND[kind] + " (rows streamed once by global_load_lds, "
+           "v_mfma_f32_16x16x32_bf16 against register-resident query fragments)",
+           "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+           "avg_kernel_ms": kms, "launches_per_step": launches_per_step, "rows_per_launch": rows,
+           "queries_per_launch": nq_launch, "algorithmic_bytes_per_launch": nbytes,
+           "traffic": pmc_traffic(KERNEL_OF_KIND[kind], config_key),
+           "traffic_source": "profiles/r03_pmc_per_dispatch.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes), key "
+                             + config_key}
+    if issued_flop:
+        out["bf16_mfma_flop_issued_per_launch"] = issued_flop
+        out["bf16_tflops_issued"] = issued_flop / (kms * 1e-3) / 1e12
+        out["bf16_tflops_issued_frac_of_2500"] = out["bf16_tflops_issued"] / 2500.0
+        out["bf16_flop_useful_per_launch"] = useful_flop
+    return out
 
 
 def recall_at(r_pruned, r_exact, ks=(1, 5, 32)):
@@ -292,7 +326,10 @@ def secondary_c5(dev, rows, D, k):
     t_c = timed_wall(lambda: hf.recall_batch(q, k=k, now=now), 3, warm=1)
     t_e = timed_wall(lambda: hf.recall_batch(q, k=k, now=now, use_candidates=False), 2, warm=1)
     s_e, r_e = hf.recall_batch(q, k=k, now=now, use_candidates=False)
-    out = {"rows": rows, "dim": D, "producer_dtype": "bf16 (stored fp32)", "write_s": t_write,
+    out = {"rows": rows, "dim": D, "producer_dtype": "bf16 (stored fp32)",
+           "write_path": "bulk_write: NO online centroid update, ONE rebuild at the end (not the reference's "
+                         "rebuild-every-512-inserts schedule; see secondary.reference_semantics_write for that path)",
+           "write_s": t_write,
            "writes_per_s": rows / t_write, "write_hbm_gbs": rows * D * (2 + 4) / t_write / 1e9,
            "rebuild_centroids_s": t_rebuild, "first_recall_incl_list_build_s": t_first, "queries": nq, "k": k,
            "centroid_index": dict(retrievals_per_s=nq / t_c, held_in_row_is_top1=float((r_c[:, 0] == pick.to(torch.int32)).float().mean()),
@@ -390,7 +427,7 @@ def main():
     rows = (args.bank_rows + world - 1) // world          # per rank
     total = rows * world
     hf = new_bank(rows, D, dev)
-    sh = ShardedHippocampus(hf, total)
+    sh = ShardedHippocampus(hf, total, force_collectives=use_dist and world == 1)
     fill_bank(hf, rows, D, 1234 + rank, dev)
     sh.memory_count = total
     sh.rebuild_centroids(perm=torch.randperm(total, generator=torch.Generator().manual_seed(7)))
@@ -442,8 +479,11 @@ def main():
     cfg_key = f"headline_{args.bank_rows}x{D}_n{world}_{'index' if cand else 'exact'}"
     # kind 3 reports the allocated sorted rows (slack and padding included); the algorithmic unit is one
     # read of every bank row
+    issued = useful = None
+    if kind == 3 and world == 1:
+        issued, useful = ivf_issued_flop(hf, q, D)
     roof = hbm_roofline(kind, kms, nprof / max(args.steps, 1), hf.memory_count if kind == 3 else rows_c.value, D,
-                        nq_c.value, cfg_key) if nprof else None
+                        nq_c.value, cfg_key, issued, useful) if nprof else None
 
     mode = ("centroid-index recall (8 nearest of 256 centroids, hippocampal.py:259-270) through inverted lists on "
             "the two-stage scan" if cand else "exact recall (two-stage scan)")
@@ -474,7 +514,8 @@ def main():
                 qq = q[:nqq].contiguous()
                 dt, kms2, lps, kind2, rws, nql = profiled(lib, lambda: hf.recall_batch(qq, k=k, now=now, use_candidates=False), 20)
                 sec[name] = {"retrievals_per_s": nqq / dt, "ms_per_step": dt * 1e3,
-                             "roofline": hbm_roofline(kind2, kms2, lps, rws, D, nql, f"exact_{args.bank_rows}x{D}")}
+                             "roofline": hbm_roofline(kind2, kms2, lps, rws, D, nql,
+                                                      f"exact_{args.bank_rows}x{D}" + ("_2048q" if nqq > 256 else ""))}
             qq = q[:256].contiguous()
             dt = timed_wall(lambda: hf.recall_batch(qq, k=k, now=now), 50)
             sec["centroid_index_recall_256q"] = {"retrievals_per_s": 256 / dt, "ms_per_step": dt * 1e3}
@@ -508,6 +549,22 @@ def main():
                     return hf.recall_batch(qb, k=5, now=now)
                 dt = timed_wall(fwd, 20)
                 sec[f"interleaved_store_retrieve_B{B}"] = {"ms_per_forward": dt * 1e3, "bank_rows": hf.memory_count}
+            # reference-semantics ingest: create_episodic_memories with the index on -- every row
+            # is assigned to its nearest centroid and moves that centroid's running mean before the next row is
+            # looked at (hippocampal.py:218-230).  The bank is full, so rows overwrite the FIFO ring and the
+            # reference's "rebuild every 512 inserts" never fires (memory_count stays put): this is the write path
+            # alone.  With the rebuild cadence of a GROWING bank the rate is bounded by the rebuild itself.
+            rs = {}
+            for B in (512, 4096):
+                newrows = torch.randn(B, D, device=dev)
+                ids = [f"w{j}" for j in range(B)]
+                dt = timed_wall(lambda: hf.create_episodic_memories(ids, newrows), 10, warm=2)
+                rs[f"rows_per_s_batches_of_{B}"] = B / dt
+            t_rb = sec["rebuild_centroids_ms"] * 1e-3
+            rs["rows_per_s_with_a_rebuild_every_512_inserts_derived"] = 512.0 / (512.0 / rs["rows_per_s_batches_of_512"] + t_rb)
+            rs["note"] = ("online nearest-centroid / running-mean update through create_episodic_memories at "
+                          f"{hf.memory_count} x {D}, index on; r02: one workgroup, 15 us per row = 6.6e4 rows/s")
+            sec["reference_semantics_write"] = rs
             out["secondary"] = sec
         if not args.no_cpu_baseline:
             s_h, r_h = hf.recall_batch(q[:args.cpu_queries].contiguous(), k=k, now=now, use_candidates=cand)
