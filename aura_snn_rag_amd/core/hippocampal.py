@@ -96,6 +96,7 @@ class _IvfState:
         self.valid = False
         # cached score constants of the sorted rows (aura_ivf2_row_constants): valid for ONE fp32 `now` (the
         # reference's fp32 timestamps give time a 128-second grain) while metadata, rho and layout are unchanged
+        self.plan = None              # ops.Ivf2Plan of this layout (validated once, see recall_batch)
         self.rowc: Optional[torch.Tensor] = None
         self.rowc_live = False
         self.rowc_now = 0.0           # the fp32 `now` the table was built for
@@ -342,6 +343,10 @@ class HippocampalFormation(nn.Module):
             self._ensure_norms()
 
     def _features_to_device(self, features, rows: Optional[int] = None) -> torch.Tensor:
+        if (rows is None and isinstance(features, torch.Tensor) and features.dtype == torch.float32 and features.dim() == 2
+                and features.device == self.memory_features.device and features.shape[1] == self.memory_features.shape[1]
+                and features.is_contiguous() and not features.requires_grad):
+            return features                       # already what the kernels take (the common case of batched recall)
         if isinstance(features, np.ndarray):
             features = torch.from_numpy(features)
         f = features.detach().to(device=self.device, dtype=torch.float32)
@@ -636,12 +641,14 @@ class HippocampalFormation(nn.Module):
             elif ivf is not None:
                 # large banks / large batches: inverted lists on the two-stage scan (every probed list is
                 # streamed once per 2048 queries from the list-sorted bf16 shadow); same rows and score bits
-                scores, rows, ovf = ops.knn_search_ivf2(self.memory_features, self._inv_norm, self.memory_metadata,
-                                                        q, kk, now, self.centroids, nprobe, ivf.sorted_bf16,
-                                                        self._rho, ivf.sorted_rows, ivf.pad_off, ivf.list_len,
-                                                        n_sorted=ivf.n_sorted, lists_flag=ivf.flag,
-                                                        probe_ids=probe_ids,
-                                                        row_constants=self._ivf_row_constants(ivf, now))
+                rowc = self._ivf_row_constants(ivf, now)
+                plan = ivf.plan
+                if plan is None or not plan.matches(self.memory_features, self.memory_metadata, self.centroids,
+                                                    ivf.sorted_bf16, ivf.n_sorted, rowc) or plan.nprobe != nprobe:
+                    plan = ivf.plan = ops.Ivf2Plan(self.memory_features, self._inv_norm, self.memory_metadata, self.centroids,
+                                                   nprobe, ivf.sorted_bf16, self._rho, ivf.sorted_rows, ivf.pad_off,
+                                                   ivf.list_len, ivf.n_sorted, ivf.flag, rowc)
+                scores, rows, ovf = plan.run(q, kk, now, probe_ids=probe_ids)
         if not exchanged:
             drain_exchanges(q.shape[0])
         if check_overflow and scores is not None:

@@ -500,7 +500,7 @@ __global__ __launch_bounds__(64) void seq_ntw_kernel(Model m, const float* __res
         //      contiguous 64 T 4-byte region) go HBM -> LDS directly (global_load_lds, 1 KiB per
         //      instruction, lane-linear): all T/4 pieces are in flight at once and no VGPR is staged
         //      (Izhikevich 2^22 x 100: 0.737 -> 0.621 ms, 4.6 -> 5.5 TB/s).
-        if (dma && nrows == 64) {
+        if ((dma & 1) && nrows == 64) {
             const float* src = I + n0 * Tn + lane * 4;
             for (int p = 0; p < w4; ++p)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + p * 256),
@@ -539,8 +539,10 @@ __global__ __launch_bounds__(64) void seq_ntw_kernel(Model m, const float* __res
         row = lane / w4; c4 = lane % w4;
         for (int p = 0; p < w4; ++p) {
             if (row < nrows) {
-                const float4 v = *reinterpret_cast<const float4*>(tile + row * S + 4 * c4);
-                *reinterpret_cast<float4*>(Sp + (n0 + row) * Tn + t0 + 4 * c4) = v;
+                float v[4];
+                Io<float, 4>::load(tile + row * S + 4 * c4, v);
+                if (dma & 2) Io<float, 4>::store_nt(Sp + (n0 + row) * Tn + t0 + 4 * c4, v);   // written once, never re-read here
+                else Io<float, 4>::store(Sp + (n0 + row) * Tn + t0 + 4 * c4, v);
             }
             row += dq; c4 += dr;
             if (c4 >= w4) { c4 -= w4; ++row; }
@@ -550,66 +552,6 @@ __global__ __launch_bounds__(64) void seq_ntw_kernel(Model m, const float* __res
     if (n < N) {
         st0[n] = ln.s0;
         if (Model::NS > 1) st1[n] = ln.s1;
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// Wave-tile form, persistent (round 3): whole 64-neuron tiles whose LDS image is the HBM image (S == W == T).
-// A single-wave block walks tiles blockIdx, blockIdx + grid, ... with TWO LDS buffers: the next tile's LDS-DMA is
-// issued before the current tile is computed, so a wave's own load latency hides behind its own compute and store
-// phases instead of relying on five other waves of the CU being in the right phase; a block also pays its launch
-// and its state prologue once per ~85 tiles instead of once per tile.  Stores are non-temporal (written once).
-// ------------------------------------------------------------------------------------------
-template <class Model>
-__global__ __launch_bounds__(64) void seq_ntw_dma_kernel(Model m, const float* __restrict__ I,
-                                                         float* __restrict__ Sp, float* st0, float* st1,
-                                                         int64_t ntiles, int T) {
-    extern __shared__ __attribute__((aligned(16))) float tile[];  // [2][64][T]
-    const int lane = threadIdx.x;
-    const int w4 = T >> 2;                                   // 1-KiB pieces per tile (T/4 odd: conflict-free rows)
-    const int64_t tile_floats = (int64_t)64 * T;
-    auto issue = [&](int64_t tl, int buf) {
-        const float* src = I + tl * tile_floats + lane * 4;
-        float* dst = tile + (int64_t)buf * tile_floats;
-        for (int p = 0; p < w4; ++p)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + p * 256),
-                                             (__attribute__((address_space(3))) void*)(dst + p * 256), 16, 0, 0);
-    };
-    int64_t tl = blockIdx.x;
-    if (tl >= ntiles) return;
-    issue(tl, 0);
-    int buf = 0;
-    for (; tl < ntiles; tl += gridDim.x, buf ^= 1) {
-        const int64_t n = tl * 64 + lane;
-        typename Model::Lane ln;
-        m.init(ln, n);
-        ln.s0 = st0[n];
-        ln.s1 = Model::NS > 1 ? st1[n] : 0.0f;
-        const int64_t nxt = tl + gridDim.x;
-        // every outstanding vector-memory operation is older than the prefetch issued below (the previous tile's
-        // stores included): wait for all of them here, THEN start the next tile's DMA
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (nxt < ntiles) issue(nxt, buf ^ 1);
-        __syncthreads();                                     // single-wave block: orders the DMA's LDS writes before the reads
-        float* const base = tile + (int64_t)buf * tile_floats;
-        float* const myrow = base + lane * T;
-        for (int j = 0; j < w4; ++j) {
-            float xin[4], spk[4];
-            Io<float, 4>::load(myrow + 4 * j, xin);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) spk[e] = m.step(ln, xin[e]);
-            Io<float, 4>::store(myrow + 4 * j, spk);
-        }
-        __syncthreads();
-        float* const out = Sp + tl * tile_floats + lane * 4;
-        for (int p = 0; p < w4; ++p) {
-            float v[4];
-            Io<float, 4>::load(base + p * 256 + lane * 4, v);
-            Io<float, 4>::store_nt(out + p * 256, v);
-        }
-        st0[n] = ln.s0;
-        if (Model::NS > 1) st1[n] = ln.s1;
-        __syncthreads();                                     // the buffer is free for the DMA of the tile after next
     }
 }
 
@@ -648,27 +590,12 @@ int launch_nt(const Model& m, const float* I, float* S, float* st0, float* st1, 
         const int64_t wblocks = (N + 63) / 64;
         if (wblocks > 0x7fffffffLL) return AURA_E_INVAL;
         static const bool no_dma = getenv("AURA_NT_NO_DMA") != nullptr;
-        const int dma = (!no_dma && Sld == W && T <= NTW_MAXW) ? 1 : 0;
-        static const bool no_persist = getenv("AURA_NT_NO_PERSIST") != nullptr;   // A/B runs: one block per tile
-        const int64_t full = N / 64;                          // whole tiles: the persistent double-buffered form
-        if (dma && !no_persist && full >= 1024) {
-            const size_t lds = (size_t)2 * 64 * W * sizeof(float);
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(seq_ntw_dma_kernel<Model>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * NTW_MAXW * 4) != hipSuccess)
-                return AURA_E_LAUNCH;
-            const int per_cu = (int)((160 * 1024) / lds);     // blocks a CU's LDS holds (3 at T = 100)
-            int64_t grid = (int64_t)256 * (per_cu < 1 ? 1 : per_cu);
-            if (grid > full) grid = full;
-            hipLaunchKernelGGL((seq_ntw_dma_kernel<Model>), dim3((unsigned)grid), dim3(64), lds, s, m, I, S, st0, st1,
-                               full, (int)T);
-            if (check_launch()) return AURA_E_LAUNCH;
-            const int64_t rest = N - full * 64;
-            if (rest > 0)
-                hipLaunchKernelGGL((seq_ntw_kernel<Model>), dim3(1), dim3(64), (size_t)64 * Sld * sizeof(float), s, m,
-                                   I + full * 64 * T, S + full * 64 * T, st0 + full * 64, st1 ? st1 + full * 64 : st1,
-                                   rest, T, W, Sld, dma);
-            return check_launch();
-        }
+        static const bool nt_st = getenv("AURA_NT_STORE_NT") != nullptr;   // A/B runs: non-temporal spike stores
+        const int dma = ((!no_dma && Sld == W && T <= NTW_MAXW) ? 1 : 0) | (nt_st ? 2 : 0);
+        // (Measured dead end, round 3: a persistent form -- single-wave blocks walking tiles with two LDS buffers,
+        //  the next tile's LDS-DMA issued before the current tile is computed -- ran 0.705 ms against 0.627 ms
+        //  for this one-block-per-tile form at 2^22 x 100: six independent waves per CU in different phases keep
+        //  more loads in flight than three double-buffered ones.)
         hipLaunchKernelGGL((seq_ntw_kernel<Model>), dim3((unsigned)wblocks), dim3(64),
                            (size_t)64 * Sld * sizeof(float), s, m, I, S, st0, st1, N, T, W, Sld, dma);
     } else if (vec)

@@ -675,6 +675,85 @@ def knn_search_ivf2(bank, inv_norm, meta, queries, k: int, now: float, centroids
     return out_s, out_i, ovf
 
 
+class Ivf2Plan:
+    """``knn_search_ivf2`` for ONE list layout, validated once: the per-call path is a shape check of the queries,
+    two output allocations and the C call.  (Between a recall's flag read and the next recall's first launch the
+    GPU idles; the generic wrapper spends ~30 us of Python there -- a dozen tensor checks, ~25 ``data_ptr()`` calls,
+    a workspace-size query -- against a 0.7 ms step.)  Built by ``HippocampalFormation`` after every re-pack of its
+    lists; any tensor of the layout being replaced invalidates the plan (the owner drops it)."""
+
+    def __init__(self, bank, inv_norm, meta, centroids, nprobe: int, sorted_shadow, rho, sorted_rows, pad_off, list_len,
+                 n_sorted: int, lists_flag, row_constants):
+        _need(bank, "bank", torch.float32); _need(inv_norm, "inv_norm", torch.float32)
+        _need(meta, "meta", torch.float32); _need(centroids, "centroids", torch.float32)
+        _need(sorted_shadow, "sorted_shadow", torch.bfloat16); _need(rho, "rho", torch.float32)
+        for t, n in ((sorted_rows, "sorted_rows"), (pad_off, "pad_off"), (list_len, "list_len"), (lists_flag, "lists_flag")):
+            _need(t, n, torch.int32)
+        _need(row_constants, "row_constants", torch.float32)
+        M, D = bank.shape
+        ns = int(n_sorted)
+        if meta.shape != (M, 4) or rho.numel() != M or centroids.shape != (256, D) or not (0 < nprobe <= 8):
+            raise ValueError("Ivf2Plan: shape mismatch")
+        if sorted_shadow.shape[1] != D or not (0 < ns <= min(sorted_rows.numel(), sorted_shadow.shape[0])) or \
+                pad_off.numel() != 257 or list_len.numel() != 256 or ns % 16 or D % 8 or D > 768:
+            raise ValueError("Ivf2Plan: layout arrays do not match")
+        if row_constants.dim() != 2 or row_constants.shape[1] != 4 or row_constants.shape[0] < ns:
+            raise ValueError("Ivf2Plan: row_constants must be [>= n_sorted, 4]")
+        self._keep = (bank, inv_norm, meta, centroids, sorted_shadow, rho, sorted_rows, pad_off, list_len, lists_flag,
+                      row_constants)
+        self.M, self.D, self.ns, self.nprobe, self.device = M, D, ns, int(nprobe), bank.device
+        self._head = tuple(t.data_ptr() for t in (bank, inv_norm, meta, sorted_shadow, rho, sorted_rows, pad_off, list_len,
+                                                  lists_flag, row_constants))
+        self._cent = centroids.data_ptr()
+        self._bytes = {}
+        self._fn = lib().aura_knn_search_ivf2
+        self._fn_probed = lib().aura_knn_search_ivf2_probed
+
+    def matches(self, bank, meta, centroids, sorted_shadow, n_sorted: int, row_constants) -> bool:
+        k = self._keep
+        return (k[0] is bank and k[2] is meta and k[3] is centroids and k[4] is sorted_shadow and k[10] is row_constants
+                and self.ns == int(n_sorted))
+
+    def run(self, queries, k: int, now: float, probe_ids=None, idx_base: int = 0):
+        if not (queries.is_cuda and queries.dtype == torch.float32 and queries.dim() == 2 and queries.shape[1] == self.D
+                and queries.is_contiguous()):
+            raise ValueError("Ivf2Plan.run: queries must be a contiguous fp32 [nq, D] tensor on the bank's device")
+        nq = queries.shape[0]
+        if not (0 < k <= 256):
+            raise ValueError("Ivf2Plan.run: k <= 256")
+        dev = self.device
+        out_s = torch.empty(nq, k, dtype=torch.float32, device=dev)
+        out_i = torch.empty(nq, k, dtype=torch.int32, device=dev)
+        if nq == 0:
+            return out_s, out_i, torch.zeros(1, dtype=torch.int32, device=dev)
+        nbytes = self._bytes.get((nq, k))
+        if nbytes is None:
+            nbytes = self._bytes[(nq, k)] = lib().aura_knn_ivf2_workspace_bytes(self.ns, nq, k)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        key = (dev, stream)
+        ws = _workspaces.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = _workspace(dev, nbytes)
+        ovf = _ovf_flags.get(key)
+        if ovf is None:
+            ovf = _overflow_flag(dev)
+        base = (ws.data_ptr() + 255) // 256 * 256
+        h = self._head
+        if probe_ids is None:
+            check(self._fn(h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], self.ns, self.M, queries.data_ptr(),
+                           now, self.D, nq, k, self._cent, self.nprobe, idx_base, out_s.data_ptr(), out_i.data_ptr(), base,
+                           nbytes, ovf.data_ptr(), stream), "aura_knn_search_ivf2")
+        else:
+            _need(probe_ids, "probe_ids", torch.int32)
+            if tuple(probe_ids.shape) != (nq, 8):
+                raise ValueError("Ivf2Plan.run: probe_ids must be [nq, 8] (centroid_probe)")
+            check(self._fn_probed(h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], self.ns, self.M,
+                                  queries.data_ptr(), now, self.D, nq, k, self._cent, self.nprobe, probe_ids.data_ptr(),
+                                  idx_base, out_s.data_ptr(), out_i.data_ptr(), base, nbytes, ovf.data_ptr(), stream),
+                  "aura_knn_search_ivf2_probed")
+        return out_s, out_i, ovf
+
+
 class Ivf2Staged:
     """``knn_search_ivf2`` in two stages (``aura_knn_search_ivf2_staged``) for one pass of at most 8192 queries:
     ``stage1(k2)`` -> bounds [nq, 2] (the k-th and the k2-th largest sampled lower bound of every query on this
