@@ -57,7 +57,7 @@ struct AdExModel {
     __device__ __forceinline__ float step(Lane& l, float i_t) const {
         float V = l.s0, w = l.s1;
         // The reference's torch.exp on CPU is Intel MKL's vmsExp (high-accuracy mode; checked bit for bit against
-        // libtorch_cpu's export over 10^6 arguments, tests/test_oracle_known_answers.py) -- closed source, within
+        // libtorch_cpu's export over 10^6 arguments by the known-answer tests) -- closed source, within
         // ~0.51 ulp.  OCML's expf (1 ulp) disagrees with it on ~10 % of the arguments, SLEEF's expf_u10 (restated
         // and checked bit for bit against libtorch's Sleef_expf16_u10 -- but that is not what torch.exp calls) on
         // 9.5 %; the CORRECTLY ROUNDED float exp on 1.07 %, each by one ulp: the closest a portable
