@@ -463,7 +463,9 @@ class HippocampalFormation(nn.Module):
         # A batch that overwrites may name a slot more than once (a full bank in the reference's mode
         # sends every write to slot 0): the last write wins, as in the reference's sequential loop.  The
         # serial centroid kernel walks the rows in order; the parallel kernel gets the survivors only.
-        keep = self._last_occurrences(slots, n_app)
+        # (appends and a FIFO ring that does not lap itself name every slot once: no need to look)
+        ring_distinct = self._overflow != 'reference' and slots.size - n_app <= self.max_memories
+        keep = None if (slots.size == n_app or ring_distinct) else self._last_occurrences(slots, n_app)
         keep_t = None if keep is None else torch.from_numpy(keep).to(self.device)
         uniq_t = slot_t if keep is None else slot_t[keep_t].contiguous()
         if keep is not None and not online:
@@ -487,8 +489,13 @@ class HippocampalFormation(nn.Module):
         self.id_to_idx.update(zip(ids, slot_list))
         if n_app:
             self._idx_to_id[c0:c0 + n_app] = list(ids[:n_app])
-        for mid, slot in zip(ids[n_app:], slot_list[n_app:]):
-            self._idx_to_id[slot] = mid
+        if len(slot_list) > n_app:
+            over = slot_list[n_app:]
+            if ring_distinct and over[-1] - over[0] == len(over) - 1:      # one contiguous run of the ring: a slice
+                self._idx_to_id[over[0]:over[-1] + 1] = list(ids[n_app:])
+            else:
+                for mid, slot in zip(ids[n_app:], over):
+                    self._idx_to_id[slot] = mid
 
     def id_of_row(self, row: int) -> Optional[str]:
         """Memory id stored at bank row ``row`` (explicit id, else the implicit bulk id)."""

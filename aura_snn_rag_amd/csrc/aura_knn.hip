@@ -283,7 +283,9 @@ __device__ __forceinline__ float centroid_dist_wave(const float* __restrict__ x,
 }
 
 constexpr int ONL_CG = 8;                   // centroids per wave task of phase A
-constexpr int ONL_CHUNK = 4096;             // rows per phase A / phase B pair (workspace: 257 floats per row)
+constexpr int ONL_CHUNK = 512;              // rows per phase A / phase B pair (workspace: 259 floats per row).  The step
+                                            // bounds only grow inside a chunk, so long chunks re-score more and more rows:
+                                            // 4096-row chunks ran at half the per-row rate of 512-row ones
 
 __global__ __launch_bounds__(256) void online_dist0_kernel(const float* __restrict__ feats,
                                                            const float* __restrict__ centroids, int eff_k,
@@ -2167,7 +2169,8 @@ struct ProfileState {
     int64_t rows = 0, nq = 0;   // rows x queries scored by the last profiled main-scan launch
     int kind = 0;               // 0 = fp32 MFMA scan, 1 = bf16 prefilter scan
 };
-ProfileState g_prof;
+ProfileState g_prof;            // one measurement session per PROCESS (bench.py / tests; aura_profile_begin documents it):
+                                // events belong to the device that was current at aura_profile_begin
 
 template <int WQ, int WR, int RT>
 int launch_scan(const ScanArgs& a_in, int mode, int64_t ntiles_grid, hipStream_t s) {
@@ -2194,15 +2197,18 @@ int launch_scan(const ScanArgs& a_in, int mode, int64_t ntiles_grid, hipStream_t
 }
 
 inline int device_cu_count() {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
+    // per DEVICE (a process that drives several GPUs gets each one's own count)
+    static std::mutex mu;
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    std::lock_guard<std::mutex> g(mu);
+    if (cus[dev] == 0) {
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus[dev] = prop.multiProcessorCount;
+        if (cus[dev] <= 0) cus[dev] = 256;
     }
-    return cus;
+    return cus[dev];
 }
 
 // persistent FILTER scan for a 256-query block (a.n_items non-sample 32-row tiles)
