@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes
 import os
 import threading
-from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_uint32, c_void_p
 from typing import Optional
 
 LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib")
@@ -28,7 +28,7 @@ KNN_FLAG_LISTS_STALE = 128     # bit of the overflow flag: the inverted lists dr
 KNN_FLAG_NO_CANDIDATES = 64   # bit of the overflow flag: a query without any candidate row (not an overflow)
 
 # name -> (restype, argtypes); mirrors include/aura_hip.h one to one
-P, I64, I32, F, I = c_void_p, c_int64, c_int32, c_float, c_int
+P, I64, I32, F, I, U32 = c_void_p, c_int64, c_int32, c_float, c_int, c_uint32
 SIGNATURES = {
     "aura_version": (c_char_p, []),
     "aura_izh_run_nt": (I, [P, P, P, P, F, F, F, F, F, I64, I64, P]),
@@ -77,6 +77,10 @@ SIGNATURES = {
                                         I64, P, P]),
     "aura_knn_search_ivf2_staged": (I, [P, P, P, P, P, P, P, P, P, P, I64, I64, P, F, I64, I64, I, P, I, P, I32, P, P, P,
                                         I64, P, I, I, P, P]),
+    "aura_host_word_alloc": (I, [P]),
+    "aura_host_word_free": (I, [P]),
+    "aura_knn_search_ivf2_signal": (I, [P, P, P, P, P, P, P, P, P, P, I64, I64, P, F, I64, I64, I, P, I, P, I32, P, P, P,
+                                        I64, P, P, U32, P]),
     "aura_profile_begin": (I, [I]),
     "aura_profile_end": (I, [P, I]),
     "aura_profile_last_scan": (I, [P, P]),

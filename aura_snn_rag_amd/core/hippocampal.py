@@ -623,7 +623,7 @@ class HippocampalFormation(nn.Module):
             return ops.knn_search(self.memory_features, self._inv_norm, self.memory_metadata, q, kk, now,
                                   shadow=shadow, rho=self._rho if shadow is not None else None, **kw)
         nprobe = min(8, self.centroids_k)
-        scores = rows = ovf = None
+        scores = rows = ovf = flag_of = None
         full_index = self.centroids.shape[0] == 256
         masked_ok = (q_loc is None and full_index and self.memory_count <= self.MASKED_SCAN_MAX_ROWS and
                      q.shape[0] <= self.MASKED_SCAN_MAX_QUERIES and bound_exchange is None)
@@ -656,12 +656,13 @@ class HippocampalFormation(nn.Module):
                                                    nprobe, ivf.sorted_bf16, self._rho, ivf.sorted_rows, ivf.pad_off,
                                                    ivf.list_len, ivf.n_sorted, ivf.flag, rowc)
                 scores, rows, ovf = plan.run(q, kk, now, probe_ids=probe_ids)
+                flag_of = plan.wait_flag                    # (the flag arrives through the plan's completion word)
         if not exchanged:
             drain_exchanges(q.shape[0])
         if check_overflow and scores is not None:
             # ONE host read for both conditions: the library's flag carries the overflow bits of the
             # two-stage lists and the "a query has no candidate at all" bit
-            f = int(ovf.item())
+            f = flag_of() if flag_of is not None else int(ovf.item())
             if f & ops.KNN_FLAG_LISTS_STALE:          # a write outgrew a list's slack: re-pack, then once more
                 self._ivf.valid = False
                 if _retry < 2 and bound_exchange is None:   # (an exchanged recall is never repeated: collectives)

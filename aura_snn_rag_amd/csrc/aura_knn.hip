@@ -2787,7 +2787,8 @@ static int knn_search_ivf2_impl(const float* bank, const float* inv_norm, const 
                          const float* centroids, int nprobe, int32_t idx_base, float* out_scores,
                          int32_t* out_idx, void* workspace, int64_t workspace_bytes,
                          int32_t* overflow_out, const int32_t* probe_ids, const float4* rowc_cached, void* stream,
-                         int stg = 0, int k2 = 0, float* bounds = nullptr) {
+                         int stg = 0, int k2 = 0, float* bounds = nullptr, uint32_t* host_word = nullptr,
+                         uint32_t host_seq = 0) {
     // stg: 0 = the whole recall; 1 = up to the sampled bounds, written to bounds[nq][2] = {k-th, k2-th largest
     // sampled lower bound}; 2 = from there on (same workspace, untouched in between), every query's threshold
     // first raised to bounds[q] (one float per query: the caller's combination of all shards' stage-1 bounds).
@@ -2855,7 +2856,7 @@ static int knn_search_ivf2_impl(const float* bank, const float* inv_norm, const 
         // per query: 1/||q||, bf16 fragments, eq; resets of the pass (per-list counters, qslot, the call's flag)
         hipLaunchKernelGGL(ivf2_qprep_kernel, dim3((unsigned)((nqb + 1 + 3) / 4)), dim3(256), 0, s,
                            qptr, (int64_t)nqb, D, KS, w.qhat, w.inv_q, w.eq_q, w.qslot, w.lq_cnt,
-                           qb0 == 0 ? overflow_out : nullptr, lists_flag);
+                           qb0 == 0 ? overflow_out : nullptr, lists_flag, w.work_counter);
         if ((rc = check_launch())) return rc;
         stage("query prep");
         // the probe launch also fills the per-list query lists (lq_cnt / lq_list); probes that the caller
@@ -2962,6 +2963,9 @@ static int knn_search_ivf2_impl(const float* bank, const float* inv_norm, const 
         r.rho = rho; r.eq = w.eq_q; r.e_fix = e_fix; r.eq_worst = coarse_eq_worst((float)D);
         r.cand_scores = w.cand_scores; r.cand_idx = w.cand_idx; r.cap = w.cap; r.idx_base = idx_base;
         r.out_scores = out_scores + qb0 * k; r.out_idx = out_idx + qb0 * k; r.overflow = overflow_out;
+        if (host_word && qb0 + w.qp >= nq) {                 // the call's last pass signals its completion to the host
+            r.done_counter = w.work_counter; r.host_word = host_word; r.host_seq = host_seq;
+        }
         if (trace) {                                         // candidate lists with row ids outside the bank
             (void)hipStreamSynchronize(s);
             std::vector<int32_t> hc((size_t)nqb * CNT_STRIDE), hi((size_t)nqb * w.cap);
@@ -3038,6 +3042,36 @@ int aura_knn_search_ivf2_probed(const float* bank, const float* inv_norm, const 
                                 n_sorted, N, queries, now, D, nq, k, centroids, nprobe, idx_base, out_scores, out_idx,
                                 workspace, workspace_bytes, overflow_out, probe_ids,
                                 reinterpret_cast<const float4*>(row_constants), stream);
+}
+
+int aura_host_word_alloc(void** host_word_out) {
+    if (!host_word_out) return AURA_E_INVAL;
+    void* p = nullptr;
+    if (hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return AURA_E_LAUNCH;
+    for (int i = 0; i < 16; ++i) static_cast<volatile uint32_t*>(p)[i] = 0u;
+    *host_word_out = p;
+    return AURA_OK;
+}
+
+int aura_host_word_free(void* host_word) {
+    if (!host_word) return AURA_OK;
+    return hipHostFree(host_word) == hipSuccess ? AURA_OK : AURA_E_LAUNCH;
+}
+
+int aura_knn_search_ivf2_signal(const float* bank, const float* inv_norm, const float* meta,
+                                const uint16_t* sorted_bf16, const float* rho, const int32_t* sorted_rows,
+                                const int32_t* pad_off, const int32_t* list_len, const int32_t* lists_flag,
+                                const float* row_constants,
+                                int64_t n_sorted, int64_t N, const float* queries, float now, int64_t D, int64_t nq,
+                                int k, const float* centroids, int nprobe, const int32_t* probe_ids, int32_t idx_base,
+                                float* out_scores, int32_t* out_idx, void* workspace, int64_t workspace_bytes,
+                                int32_t* overflow_out, uint32_t* host_word, uint32_t host_seq, void* stream) {
+    if (!host_word || !overflow_out) return AURA_E_INVAL;
+    if (reinterpret_cast<uintptr_t>(row_constants) & 15) return AURA_E_ALIGN;
+    return knn_search_ivf2_impl(bank, inv_norm, meta, sorted_bf16, rho, sorted_rows, pad_off, list_len, lists_flag,
+                                n_sorted, N, queries, now, D, nq, k, centroids, nprobe, idx_base, out_scores, out_idx,
+                                workspace, workspace_bytes, overflow_out, probe_ids,
+                                reinterpret_cast<const float4*>(row_constants), stream, 0, 0, nullptr, host_word, host_seq);
 }
 
 int aura_knn_search_ivf2_staged(const float* bank, const float* inv_norm, const float* meta,

@@ -1076,6 +1076,12 @@ struct RefineArgs {
     int32_t* out_idx;
     int32_t* overflow;
     float* dbg_out;             // AURA_CS_DBG bit 128: [nq][8] phase times (100 MHz ticks), n, S
+    // completion word (optional): the LAST workgroup to finish publishes the call's flag and `host_seq` into
+    // host-mapped memory, so the caller learns the flag by polling two words instead of a device-to-host copy
+    // and a stream synchronisation (aura_knn_search_ivf2_signal)
+    int32_t* done_counter;      // device, zero at launch
+    volatile uint32_t* host_word;   // host-mapped: [0] = flag, [1] = sequence number
+    uint32_t host_seq;
 };
 
 template <int RF_ROWS, int RF_KC>
@@ -1275,6 +1281,20 @@ __global__ __launch_bounds__(RF_THREADS) void coarse_refine_kernel(const RefineA
             float* const o = a.dbg_out + (int64_t)q * 8;
             for (int i = 0; i < 6; ++i) o[i] = (float)(tst[i + 1] - tst[i]);
             o[6] = (float)n; o[7] = (float)S;
+        }
+    }
+    if (a.host_word) {
+        __syncthreads();                                     // this workgroup's results and flag bits are issued
+        if (tid == 0) {
+            __threadfence();                                 // ... and visible device-wide before the count
+            const int old = atomicAdd(a.done_counter, 1);
+            if (old == (int)gridDim.x - 1) {                 // every other workgroup has counted: the flag is final
+                const int f = a.overflow ? atomicAdd(a.overflow, 0) : 0;
+                a.host_word[0] = (uint32_t)f;
+                __threadfence_system();
+                a.host_word[1] = a.host_seq;
+                __threadfence_system();
+            }
         }
     }
 }

@@ -139,11 +139,13 @@ __global__ __launch_bounds__(256) void ivf2_qprep_kernel(const float* __restrict
                                                          uint16_t* __restrict__ qfrag, float* __restrict__ inv,
                                                          float* __restrict__ eq_q, int32_t* __restrict__ qslot,
                                                          int32_t* __restrict__ lq_cnt, int32_t* overflow,
-                                                         const int32_t* __restrict__ lists_flag) {
+                                                         const int32_t* __restrict__ lists_flag,
+                                                         int32_t* __restrict__ done_counter) {
     const int lane = threadIdx.x & 63;
     const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (blockIdx.x == 0) {
         lq_cnt[threadIdx.x] = 0;
+        if (threadIdx.x == 0) done_counter[0] = 0;          // (the refine launch's completion count)
         // reset of the call's flag; bit 7: aura_ivf2_append dropped a row because a list had no slack left
         if (overflow && threadIdx.x == 0) *overflow = (lists_flag && *lists_flag) ? AURA_KNN_FLAG_LISTS_STALE : 0;
     }

@@ -706,8 +706,41 @@ class Ivf2Plan:
                                                   lists_flag, row_constants))
         self._cent = centroids.data_ptr()
         self._bytes = {}
-        self._fn = lib().aura_knn_search_ivf2
-        self._fn_probed = lib().aura_knn_search_ivf2_probed
+        self._fn = lib().aura_knn_search_ivf2_signal
+        # completion word: the call's last workgroup stores the flag and a sequence number into host-mapped memory;
+        # wait_flag polls it -- no device-to-host copy, no stream synchronisation (aura_knn_search_ivf2_signal)
+        hw = ctypes.c_void_p()
+        check(lib().aura_host_word_alloc(ctypes.byref(hw)), "aura_host_word_alloc")
+        self._hw_ptr = hw.value
+        self._hw = (ctypes.c_uint32 * 2).from_address(hw.value)
+        self._seq = 0
+        self._last_ovf = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_hw_ptr", None):
+                torch.cuda.synchronize(self.device)          # no launch may still hold the word
+                lib().aura_host_word_free(self._hw_ptr)
+                self._hw_ptr = None
+        except Exception:
+            pass
+
+    def wait_flag(self, timeout_s: float = 5.0) -> int:
+        """The flag of the last ``run`` (blocks until that call's last launch has finished)."""
+        import time as _t
+        hw, seq = self._hw, self._seq
+        if hw[1] != seq:
+            t_end = None
+            n = 0
+            while hw[1] != seq:
+                n += 1
+                if (n & 0xfff) == 0:                         # every ~4000 polls: give up after timeout_s
+                    now = _t.perf_counter()
+                    if t_end is None:
+                        t_end = now + timeout_s
+                    elif now > t_end:
+                        return int(self._last_ovf.item())     # (never seen: the ordinary read still works)
+        return int(hw[0])
 
     def matches(self, bank, meta, centroids, sorted_shadow, n_sorted: int, row_constants) -> bool:
         k = self._keep
@@ -739,18 +772,17 @@ class Ivf2Plan:
             ovf = _overflow_flag(dev)
         base = (ws.data_ptr() + 255) // 256 * 256
         h = self._head
-        if probe_ids is None:
-            check(self._fn(h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], self.ns, self.M, queries.data_ptr(),
-                           now, self.D, nq, k, self._cent, self.nprobe, idx_base, out_s.data_ptr(), out_i.data_ptr(), base,
-                           nbytes, ovf.data_ptr(), stream), "aura_knn_search_ivf2")
-        else:
+        pid = None
+        if probe_ids is not None:
             _need(probe_ids, "probe_ids", torch.int32)
             if tuple(probe_ids.shape) != (nq, 8):
                 raise ValueError("Ivf2Plan.run: probe_ids must be [nq, 8] (centroid_probe)")
-            check(self._fn_probed(h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], self.ns, self.M,
-                                  queries.data_ptr(), now, self.D, nq, k, self._cent, self.nprobe, probe_ids.data_ptr(),
-                                  idx_base, out_s.data_ptr(), out_i.data_ptr(), base, nbytes, ovf.data_ptr(), stream),
-                  "aura_knn_search_ivf2_probed")
+            pid = probe_ids.data_ptr()
+        self._seq = (self._seq + 1) & 0x7fffffff or 1
+        self._last_ovf = ovf
+        check(self._fn(h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], self.ns, self.M, queries.data_ptr(),
+                       now, self.D, nq, k, self._cent, self.nprobe, pid, idx_base, out_s.data_ptr(), out_i.data_ptr(), base,
+                       nbytes, ovf.data_ptr(), self._hw_ptr, self._seq, stream), "aura_knn_search_ivf2_signal")
         return out_s, out_i, ovf
 
 

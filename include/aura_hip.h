@@ -318,6 +318,24 @@ int aura_knn_search_ivf2_probed(const float* bank, const float* inv_norm, const 
                                 float* out_scores, int32_t* out_idx, void* workspace, int64_t workspace_bytes,
                                 int32_t* overflow_out, void* stream);
 
+/* aura_knn_search_ivf2[_probed] (probe_ids may be NULL) that also tells the HOST when the call is done and what
+ * its flag is, without a device-to-host copy: host_word is 64 bytes of host-mapped memory from
+ * aura_host_word_alloc; the last workgroup of the call's last launch stores the flag into host_word[0] and then
+ * host_seq into host_word[1].  The caller polls host_word[1] == host_seq (choose a new host_seq per call) and reads
+ * the flag from host_word[0]; results are then final on the stream as after any launch.  One call in flight per
+ * host_word.  (The flag read costs the reference-style caller a stream synchronisation per recall otherwise:
+ * hippocampal.py's retrieval is synchronous too, every .item() in :311-317 waits for the GPU.) */
+int aura_host_word_alloc(void** host_word_out);
+int aura_host_word_free(void* host_word);
+int aura_knn_search_ivf2_signal(const float* bank, const float* inv_norm, const float* meta,
+                                const uint16_t* sorted_bf16, const float* rho, const int32_t* sorted_rows,
+                                const int32_t* pad_off, const int32_t* list_len, const int32_t* lists_flag,
+                                const float* row_constants,
+                                int64_t n_sorted, int64_t N, const float* queries, float now, int64_t D, int64_t nq,
+                                int k, const float* centroids, int nprobe, const int32_t* probe_ids, int32_t idx_base,
+                                float* out_scores, int32_t* out_idx, void* workspace, int64_t workspace_bytes,
+                                int32_t* overflow_out, uint32_t* host_word, uint32_t host_seq, void* stream);
+
 /* aura_knn_search_ivf2[_probed] in two stages, for a bank that is row-sharded over ranks: the
  * prefilter's threshold of a query is a lower bound of its k-th best score, and bounds found on different
  * shards can be combined before any shard filters -- every shard then keeps about 1/S of the candidates
