@@ -28,6 +28,7 @@ Reference defects on this path (SURVEY.md 8a "hazards") and what this class does
 """
 from __future__ import annotations
 
+import os
 import time
 from dataclasses import dataclass, field
 from collections.abc import Mapping
@@ -74,6 +75,10 @@ class _EpisodicView(Mapping):
 
     def __contains__(self, mid) -> bool:
         return mid in self._o.id_to_idx
+
+
+# AURA_NO_HOST_WORD=1: read the recall's flag with a device-to-host copy instead of polling the completion word (A/B runs)
+_NO_HOST_WORD = os.environ.get("AURA_NO_HOST_WORD") is not None
 
 
 class _IvfState:
@@ -656,7 +661,8 @@ class HippocampalFormation(nn.Module):
                                                    nprobe, ivf.sorted_bf16, self._rho, ivf.sorted_rows, ivf.pad_off,
                                                    ivf.list_len, ivf.n_sorted, ivf.flag, rowc)
                 scores, rows, ovf = plan.run(q, kk, now, probe_ids=probe_ids)
-                flag_of = plan.wait_flag                    # (the flag arrives through the plan's completion word)
+                if not _NO_HOST_WORD:
+                    flag_of = plan.wait_flag                # (the flag arrives through the plan's completion word)
         if not exchanged:
             drain_exchanges(q.shape[0])
         if check_overflow and scores is not None:
