@@ -2103,6 +2103,7 @@ struct Workspace {
     float* gmax;         // [qb][THR_MAX_GROUPS]
     uint16_t* qhat;      // [qb rounded up to 256][768] bf16 query fragments (two-stage path)
     float4* rowc;        // [N] per-row score constants (two-stage path)
+    int32_t* heavy;      // [qp] refine: queries left to the workgroup-per-query kernel
     int cap, cap2;
     int qp;              // queries per pass
     int64_t bytes;
@@ -2146,6 +2147,7 @@ inline Workspace carve(void* base, int64_t N, int64_t nq, int k) {
     w.gmax = reinterpret_cast<float*>(take((int64_t)qb * THR_MAX_GROUPS * 4));
     w.qhat = reinterpret_cast<uint16_t*>(take(((int64_t)qb + 255) / 256 * 256 * 768 * 2));
     w.rowc = reinterpret_cast<float4*>(take((N > 0 ? N : 1) * 16));
+    w.heavy = reinterpret_cast<int32_t*>(take((int64_t)qb * 4));
     w.bytes = off;
     return w;
 }
@@ -2250,8 +2252,23 @@ inline int dispatch_scan(const ScanArgs& a, int mode, int64_t ntiles_grid, hipSt
 #include "aura_knn_ivf2.inl"
 
 // coarse_refine_kernel in the geometry that fits the pass (see the comment at the kernel)
-inline int launch_refine_for(const RefineArgs& r, int nqb, int64_t D, int cus, hipStream_t s) {
+inline int launch_refine_for(const RefineArgs& r_in, int nqb, int64_t D, int cus, hipStream_t s, int32_t* heavy) {
     const int64_t Dpad = (D + 31) / 32 * 32;
+    RefineArgs r = r_in;
+    // Passes of many queries: one WAVE per query first (coarse_refine_wave_kernel); the workgroup-per-query kernel
+    // then only works on the queries that one marked heavy.  AURA_RF_WAVE=0 / 1: never / always (A/B runs).
+    static const int wave_mode = getenv("AURA_RF_WAVE") ? atoi(getenv("AURA_RF_WAVE")) : -1;
+    const bool use_wave = heavy && !r.dbg_out && (wave_mode == 1 || (wave_mode != 0 && nqb > 2 * cus));
+    if (use_wave) {
+        const size_t region = (size_t)Dpad * 4 + (size_t)RW_ROWS * (RW_KC + 4) * 4 + (size_t)RW_SURV * 12;
+        const size_t lds_w = 8 * region;
+        if (lds_w <= 150 * 1024) {
+            if (ensure_lds_attr(reinterpret_cast<const void*>(coarse_refine_wave_kernel), 150 * 1024)) return AURA_E_LAUNCH;
+            r.heavy = heavy;
+            hipLaunchKernelGGL(coarse_refine_wave_kernel, dim3((unsigned)((nqb + 7) / 8)), dim3(RF_THREADS), lds_w, s, r, nqb);
+            if (check_launch()) return AURA_E_LAUNCH;
+        }
+    }
     auto launch_refine = [&](auto rows_tag, auto kc_tag) -> int {
         constexpr int ROWS = decltype(rows_tag)::value, KC = decltype(kc_tag)::value;
         size_t lds = (size_t)8 * ROWS * (KC + 4) * 4 + (size_t)Dpad * 4;
@@ -2426,7 +2443,7 @@ inline int run_coarse_pass(const float* bank, const uint16_t* bank16, const floa
     static int rtm_left = 3;                                 // AURA_CS_DBG bit 128: refine phase times
     const bool rtm = (cs_dbg & 128) && rtm_left > 0;
     if (rtm) r.dbg_out = w.gmax;
-    if ((rc = launch_refine_for(r, nqb, D, cus, s))) return rc;
+    if ((rc = launch_refine_for(r, nqb, D, cus, s, w.heavy))) return rc;
     if (rtm) {
         --rtm_left;
         print_refine_phases(s, w.gmax, nqb, "full scan");
@@ -2991,7 +3008,7 @@ static int knn_search_ivf2_impl(const float* bank, const float* inv_norm, const 
         static int rtm2_left = 2;                            // AURA_CS_DBG bit 128: refine phase times
         const bool rtm2 = (cs_dbg & 128) && rtm2_left > 0;
         if (rtm2) r.dbg_out = w.gmax;
-        if ((rc = launch_refine_for(r, nqb, D, cus, s))) return rc;
+        if ((rc = launch_refine_for(r, nqb, D, cus, s, w.heavy))) return rc;
         if (rtm2) {
             --rtm2_left;
             print_refine_phases(s, w.gmax, nqb, "inverted lists");

@@ -1079,10 +1079,205 @@ struct RefineArgs {
     // completion word (optional): the LAST workgroup to finish publishes the call's flag and `host_seq` into
     // host-mapped memory, so the caller learns the flag by polling two words instead of a device-to-host copy
     // and a stream synchronisation (aura_knn_search_ivf2_signal)
+    int32_t* heavy;             // optional [nq]: written by coarse_refine_wave_kernel (1 = this query needs the
+                                // workgroup-per-query kernel), read by coarse_refine_kernel (0 = already done)
     int32_t* done_counter;      // device, zero at launch
     volatile uint32_t* host_word;   // host-mapped: [0] = flag, [1] = sequence number
     uint32_t host_seq;
 };
+
+// completion word: the LAST workgroup of the launch publishes the call's flag (see RefineArgs)
+__device__ __forceinline__ void refine_signal_done(const RefineArgs& a, int tid) {
+    if (!a.host_word) return;
+    __syncthreads();                                         // this workgroup's results and flag bits are issued
+    if (tid == 0) {
+        __threadfence();                                     // ... and visible device-wide before the count
+        const int old = atomicAdd(a.done_counter, 1);
+        if (old == (int)gridDim.x - 1) {                     // every other workgroup has counted: the flag is final
+            const int f = a.overflow ? atomicAdd(a.overflow, 0) : 0;
+            a.host_word[0] = (uint32_t)f;
+            __threadfence_system();
+            a.host_word[1] = a.host_seq;
+            __threadfence_system();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Refine, one WAVE per query (round 3) -- for passes of many queries.  The workgroup-per-query kernel below
+// spends ~11 of its ~28 us per query in phases that are pure latency for 512 threads (two dependent gathers for
+// the candidates' error terms, four radix passes with 16 barriers for T2, the query load) and holds at most two
+// queries per CU.  Here a wave keeps its query's candidates in registers (up to RW_CAND per lane), finds T2 by a
+// 32-step ballot search, re-scores its survivors RW_ROWS at a time through a private LDS stage with the SAME
+// arithmetic (fmaf order of the MFMA chain, same epilogue expressions: bit-identical scores), ranks and writes.
+// No workgroup barrier anywhere: 16 queries per CU in flight, each one's latencies hidden by the other fifteen.
+// A query with more than 64 RW_CAND candidates or more than RW_SURV survivors is marked `heavy` and left to the
+// kernel below (launched right after over the same queries; it returns at once for the others).
+// ------------------------------------------------------------------------------------------
+constexpr int RW_CAND = 16;              // candidates per lane
+constexpr int RW_SURV = 128;             // survivors per query
+constexpr int RW_ROWS = 6, RW_KC = 192;  // survivors per round x k-chunk of the private stage
+
+__global__ __launch_bounds__(RF_THREADS) void coarse_refine_wave_kernel(const RefineArgs a, int nq) {
+    extern __shared__ __attribute__((aligned(16))) char rwmem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int q = blockIdx.x * 8 + wave;
+    if (q >= nq) return;
+    const int64_t D = a.D;
+    const int64_t Dpad = (D + 31) / 32 * 32;
+    constexpr int RSTRIDE = RW_KC + 4;
+    const size_t region = (size_t)Dpad * 4 + (size_t)RW_ROWS * RSTRIDE * 4 + (size_t)RW_SURV * 12;
+    char* const base = rwmem + (size_t)wave * region;
+    float* const s_q = reinterpret_cast<float*>(base);
+    float* const s_rows = s_q + Dpad;
+    unsigned long long* const s_key = reinterpret_cast<unsigned long long*>(s_rows + RW_ROWS * RSTRIDE);
+    int32_t* const s_surv = reinterpret_cast<int32_t*>(s_key + RW_SURV);
+
+    const int n = a.cnt[(int64_t)q * CNT_STRIDE];
+    const int capn = a.cap < RF_CAP ? a.cap : RF_CAP;
+    if (n > capn || n > RW_CAND * 64) {                      // (overflowing lists are the other kernel's to report)
+        if (lane == 0) a.heavy[q] = 1;
+        return;
+    }
+    const int nj = (n + 63) >> 6;                            // registers in use (wave-uniform)
+    const float eqq = a.rho ? a.eq[q] : 0.0f;
+    float cu[RW_CAND];
+    int32_t cr[RW_CAND];
+    uint32_t cl[RW_CAND];
+#pragma unroll
+    for (int j = 0; j < RW_CAND; ++j) {
+        cu[j] = -INFINITY; cr[j] = 0; cl[j] = 0u;
+        if (j < nj) {
+            const int i = j * 64 + lane;
+            if (i < n) {
+                float u = a.cand_scores[(int64_t)q * a.cap + i];
+                int32_t r = a.cand_idx[(int64_t)q * a.cap + i];
+                if ((uint32_t)r >= (uint32_t)a.N) {          // never a valid row: fail loudly (bit 4), do not fault
+                    if (a.overflow) atomicOr(a.overflow, 16);
+                    r = 0; u = -INFINITY;
+                }
+                const float strength = a.meta[(int64_t)r * 4];
+                float err = 0.5f * a.e_cos * fabsf(strength);
+                if (a.rho)
+                    err = 0.5f * fabsf(strength) * (a.rho[r] + a.e_fix + (strength < 0.0f ? 2.0f * a.eq_worst : eqq));
+                cu[j] = u; cr[j] = r; cl[j] = ord_key(u - 2.0f * err);
+            }
+        }
+    }
+    // ---- T2 = k-th largest L (everything survives if n < k) ----
+    uint32_t t2 = 0u;
+    if (n >= a.k) {
+        for (int bit = 31; bit >= 0; --bit) {
+            const uint32_t cand = t2 | (1u << bit);
+            int c = 0;
+#pragma unroll
+            for (int j = 0; j < RW_CAND; ++j)
+                if (j < nj) c += (int)__popcll(__ballot(j * 64 + lane < n && cl[j] >= cand));
+            if (c >= a.k) t2 = cand;
+        }
+    }
+    // ---- survivors: U >= T2, compacted in candidate order ----
+    int S = 0;
+#pragma unroll
+    for (int j = 0; j < RW_CAND; ++j) {
+        if (j < nj) {
+            const bool pass = j * 64 + lane < n && ord_key(cu[j]) >= t2;
+            const unsigned long long m = __ballot(pass);
+            if (pass) {
+                const int p = S + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                if (p < RW_SURV) s_surv[p] = cr[j];
+            }
+            S += (int)__popcll(m);
+        }
+    }
+    if (S > RW_SURV) {
+        if (lane == 0) a.heavy[q] = 1;
+        return;
+    }
+    if (lane == 0) {
+        a.heavy[q] = 0;
+        if (S == 0 && a.overflow) atomicOr(a.overflow, AURA_KNN_FLAG_NO_CANDIDATES);   // (not an overflow)
+    }
+    // ---- the query, zero padded to Dpad ----
+    for (int64_t i = lane; i < Dpad; i += 64) s_q[i] = i < D ? a.queries[(int64_t)q * D + i] : 0.0f;
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const float iq = a.inv_q[q];
+    const bool ld_lane = lane * 4 < RW_KC;                   // lanes that move a row chunk
+    // ---- exact re-scoring, RW_ROWS survivors per round; k order of the fp32 scan (knn_scan_filter_v2): inside
+    //      each group of 8 consecutive k the MFMA chain visits 0,4,1,5,2,6,3,7; D padded with zeros to 32 ----
+    for (int b0 = 0; b0 < S; b0 += RW_ROWS) {
+        const int cntw = (S - b0) < RW_ROWS ? (S - b0) : RW_ROWS;
+        const float* rowp[RW_ROWS];
+#pragma unroll
+        for (int r = 0; r < RW_ROWS; ++r)
+            rowp[r] = (r < cntw && ld_lane) ? a.bank + (int64_t)s_surv[b0 + r] * D + lane * 4 : nullptr;
+        float4 pre[RW_ROWS];
+        auto fetch = [&](int64_t k0) {
+#pragma unroll
+            for (int r = 0; r < RW_ROWS; ++r) {
+                pre[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (rowp[r] && k0 + lane * 4 < D) pre[r] = *reinterpret_cast<const float4*>(rowp[r] + k0);
+            }
+        };
+        float acc = 0.0f;
+        fetch(0);
+        for (int64_t k0 = 0; k0 < Dpad; k0 += RW_KC) {
+            const int kc = (int)((Dpad - k0) < RW_KC ? (Dpad - k0) : RW_KC);
+            if (ld_lane) {
+#pragma unroll
+                for (int r = 0; r < RW_ROWS; ++r)
+                    *reinterpret_cast<float4*>(s_rows + r * RSTRIDE + lane * 4) = pre[r];
+            }
+            if (k0 + RW_KC < Dpad) fetch(k0 + RW_KC);        // next chunk flies during the chain
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane < RW_ROWS) {
+                const float* rp = s_rows + lane * RSTRIDE;
+                const float* qp = s_q + k0;
+#pragma unroll 4
+                for (int kk = 0; kk < kc; kk += 8) {
+                    const float4 b0v = *reinterpret_cast<const float4*>(rp + kk);
+                    const float4 b1v = *reinterpret_cast<const float4*>(rp + kk + 4);
+                    const float4 q0 = *reinterpret_cast<const float4*>(qp + kk);
+                    const float4 q1 = *reinterpret_cast<const float4*>(qp + kk + 4);
+                    acc = fmaf(q0.x, b0v.x, acc); acc = fmaf(q1.x, b1v.x, acc);
+                    acc = fmaf(q0.y, b0v.y, acc); acc = fmaf(q1.y, b1v.y, acc);
+                    acc = fmaf(q0.z, b0v.z, acc); acc = fmaf(q1.z, b1v.z, acc);
+                    acc = fmaf(q0.w, b0v.w, acc); acc = fmaf(q1.w, b1v.w, acc);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        if (lane < cntw) {
+            const int si = b0 + lane;
+            const int32_t row = s_surv[si];
+            const float inv_m = a.inv_norm[row];
+            const float4 m = *reinterpret_cast<const float4*>(a.meta + (int64_t)row * 4);
+            const float tw = 0.2f * expf(-(a.now - m.y) / 3600.0f);
+            const float sim = acc * iq * inv_m;
+            const float comb = (0.5f * sim + tw) * m.x;
+            s_key[si] = ((unsigned long long)ord_key(comb) << 32) | (uint32_t)(~(uint32_t)row);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // ---- rank the survivors' exact keys (all distinct) and write the top k, sorted ----
+    for (int i = lane; i < S; i += 64) {
+        const unsigned long long mine = s_key[i];
+        int rank = 0;
+        for (int j2 = 0; j2 < S; ++j2) rank += s_key[j2] > mine ? 1 : 0;
+        if (rank < a.k) {
+            a.out_scores[(int64_t)q * a.k + rank] = ord_unkey((uint32_t)(mine >> 32));
+            a.out_idx[(int64_t)q * a.k + rank] = (int32_t)(~(uint32_t)mine) + a.idx_base;
+        }
+    }
+    for (int i = S + lane; i < a.k; i += 64) {               // fewer than k rows can score
+        a.out_scores[(int64_t)q * a.k + i] = -INFINITY;
+        a.out_idx[(int64_t)q * a.k + i] = -1;
+    }
+}
 
 template <int RF_ROWS, int RF_KC>
 __global__ __launch_bounds__(RF_THREADS) void coarse_refine_kernel(const RefineArgs a) {
@@ -1102,6 +1297,10 @@ __global__ __launch_bounds__(RF_THREADS) void coarse_refine_kernel(const RefineA
     const int wave = tid >> 6, lane = tid & 63;
     const int64_t D = a.D;
     const bool tm = a.dbg_out != nullptr;
+    if (a.heavy && a.heavy[q] == 0) {                        // finished by coarse_refine_wave_kernel
+        refine_signal_done(a, tid);
+        return;
+    }
     uint32_t tst[7] = {0u, 0u, 0u, 0u, 0u, 0u, 0u};
     auto stamp = [&](int i) { if (tm) tst[i] = (uint32_t)__builtin_amdgcn_s_memrealtime(); };
     stamp(0);
@@ -1283,20 +1482,7 @@ __global__ __launch_bounds__(RF_THREADS) void coarse_refine_kernel(const RefineA
             o[6] = (float)n; o[7] = (float)S;
         }
     }
-    if (a.host_word) {
-        __syncthreads();                                     // this workgroup's results and flag bits are issued
-        if (tid == 0) {
-            __threadfence();                                 // ... and visible device-wide before the count
-            const int old = atomicAdd(a.done_counter, 1);
-            if (old == (int)gridDim.x - 1) {                 // every other workgroup has counted: the flag is final
-                const int f = a.overflow ? atomicAdd(a.overflow, 0) : 0;
-                a.host_word[0] = (uint32_t)f;
-                __threadfence_system();
-                a.host_word[1] = a.host_seq;
-                __threadfence_system();
-            }
-        }
-    }
+    refine_signal_done(a, tid);
 }
 
 inline bool coarse_eligible(const float* bank, const uint16_t* bank16, const float* queries, const float* loc_q,

@@ -321,7 +321,7 @@ struct Ivf2Workspace {
     // two-stage inverted lists
     int32_t* blk_off; int32_t* blk_list; int32_t* blk_row0; int32_t* blk_stride; int32_t* blk_nq; int32_t* item_off; int32_t* sitem_off; int32_t* nblk;
     int32_t* slotq; int32_t* qslot; uint32_t* thr; float* gmax; uint16_t* qhat; float4* rowc;
-    float* eq_slot; float* eq_q;
+    float* eq_slot; float* eq_q; int32_t* heavy;
     int cap; int qp; int64_t bytes;
 };
 
@@ -366,6 +366,7 @@ static Ivf2Workspace carve_ivf2(void* base, int64_t Npad, int64_t nq, int k) {
     w.gmax = reinterpret_cast<float*>(take(mb * 256 * 2 * ivf2_stiles(Npad) * 4));
     w.qhat = reinterpret_cast<uint16_t*>(take((qp + 1) * 768 * 2));   // one fragment set per query + the zero entry
     w.rowc = reinterpret_cast<float4*>(take((Npad > 0 ? Npad : 1) * 16));
+    w.heavy = reinterpret_cast<int32_t*>(take(qp * 4));
     w.bytes = off;
     return w;
 }
