@@ -2147,7 +2147,7 @@ inline Workspace carve(void* base, int64_t N, int64_t nq, int k) {
     w.gmax = reinterpret_cast<float*>(take((int64_t)qb * THR_MAX_GROUPS * 4));
     w.qhat = reinterpret_cast<uint16_t*>(take(((int64_t)qb + 255) / 256 * 256 * 768 * 2));
     w.rowc = reinterpret_cast<float4*>(take((N > 0 ? N : 1) * 16));
-    w.heavy = reinterpret_cast<int32_t*>(take((int64_t)qb * 4));
+    w.heavy = reinterpret_cast<int32_t*>(take(((int64_t)qb + 1) * 4));
     w.bytes = off;
     return w;
 }
@@ -2265,10 +2265,12 @@ inline int launch_refine_for(const RefineArgs& r_in, int nqb, int64_t D, int cus
         if (lds_w <= 150 * 1024) {
             if (ensure_lds_attr(reinterpret_cast<const void*>(coarse_refine_wave_kernel), 150 * 1024)) return AURA_E_LAUNCH;
             r.heavy = heavy;
+            if (hipMemsetAsync(heavy, 0, 4, s) != hipSuccess) return AURA_E_LAUNCH;
             hipLaunchKernelGGL(coarse_refine_wave_kernel, dim3((unsigned)((nqb + 7) / 8)), dim3(RF_THREADS), lds_w, s, r, nqb);
             if (check_launch()) return AURA_E_LAUNCH;
         }
     }
+    const int grid_q = r.heavy ? (nqb < 2 * cus ? nqb : 2 * cus) : nqb;   // heavy list: a small grid walks it
     auto launch_refine = [&](auto rows_tag, auto kc_tag) -> int {
         constexpr int ROWS = decltype(rows_tag)::value, KC = decltype(kc_tag)::value;
         size_t lds = (size_t)8 * ROWS * (KC + 4) * 4 + (size_t)Dpad * 4;
@@ -2276,7 +2278,7 @@ inline int launch_refine_for(const RefineArgs& r_in, int nqb, int64_t D, int cus
         if (ensure_lds_attr(reinterpret_cast<const void*>(coarse_refine_kernel<ROWS, KC>),
                             8 * ROWS * (KC + 4) * 4 + 768 * 4))
             return AURA_E_LAUNCH;
-        hipLaunchKernelGGL((coarse_refine_kernel<ROWS, KC>), dim3((unsigned)nqb), dim3(RF_THREADS), lds, s, r);
+        hipLaunchKernelGGL((coarse_refine_kernel<ROWS, KC>), dim3((unsigned)grid_q), dim3(RF_THREADS), lds, s, r);
         return check_launch();
     };
     static const int geom = getenv("AURA_RF_GEOM") ? atoi(getenv("AURA_RF_GEOM")) : 0;   // A/B runs

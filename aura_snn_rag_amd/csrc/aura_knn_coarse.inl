@@ -1079,8 +1079,8 @@ struct RefineArgs {
     // completion word (optional): the LAST workgroup to finish publishes the call's flag and `host_seq` into
     // host-mapped memory, so the caller learns the flag by polling two words instead of a device-to-host copy
     // and a stream synchronisation (aura_knn_search_ivf2_signal)
-    int32_t* heavy;             // optional [nq]: written by coarse_refine_wave_kernel (1 = this query needs the
-                                // workgroup-per-query kernel), read by coarse_refine_kernel (0 = already done)
+    int32_t* heavy;             // optional [1 + nq]: heavy[0] = number of queries coarse_refine_wave_kernel left to the
+                                // workgroup-per-query kernel (zero before that launch), heavy[1..] = those queries
     int32_t* done_counter;      // device, zero at launch
     volatile uint32_t* host_word;   // host-mapped: [0] = flag, [1] = sequence number
     uint32_t host_seq;
@@ -1111,8 +1111,8 @@ __device__ __forceinline__ void refine_signal_done(const RefineArgs& a, int tid)
 // 32-step ballot search, re-scores its survivors RW_ROWS at a time through a private LDS stage with the SAME
 // arithmetic (fmaf order of the MFMA chain, same epilogue expressions: bit-identical scores), ranks and writes.
 // No workgroup barrier anywhere: 16 queries per CU in flight, each one's latencies hidden by the other fifteen.
-// A query with more than 64 RW_CAND candidates or more than RW_SURV survivors is marked `heavy` and left to the
-// kernel below (launched right after over the same queries; it returns at once for the others).
+// A query with more than 64 RW_CAND candidates or more than RW_SURV survivors goes on the `heavy` list and is left
+// to the kernel below, launched right after with a small grid that walks that list (usually empty).
 // ------------------------------------------------------------------------------------------
 constexpr int RW_CAND = 16;              // candidates per lane
 constexpr int RW_SURV = 128;             // survivors per query
@@ -1136,7 +1136,7 @@ __global__ __launch_bounds__(RF_THREADS) void coarse_refine_wave_kernel(const Re
     const int n = a.cnt[(int64_t)q * CNT_STRIDE];
     const int capn = a.cap < RF_CAP ? a.cap : RF_CAP;
     if (n > capn || n > RW_CAND * 64) {                      // (overflowing lists are the other kernel's to report)
-        if (lane == 0) a.heavy[q] = 1;
+        if (lane == 0) a.heavy[1 + atomicAdd(a.heavy, 1)] = q;
         return;
     }
     const int nj = (n + 63) >> 6;                            // registers in use (wave-uniform)
@@ -1144,24 +1144,30 @@ __global__ __launch_bounds__(RF_THREADS) void coarse_refine_wave_kernel(const Re
     float cu[RW_CAND];
     int32_t cr[RW_CAND];
     uint32_t cl[RW_CAND];
+    // two phases, so that every load of a phase is in flight at once (a load of the error terms behind each
+    // candidate's own load would be nj round trips in a row)
 #pragma unroll
     for (int j = 0; j < RW_CAND; ++j) {
         cu[j] = -INFINITY; cr[j] = 0; cl[j] = 0u;
-        if (j < nj) {
-            const int i = j * 64 + lane;
-            if (i < n) {
-                float u = a.cand_scores[(int64_t)q * a.cap + i];
-                int32_t r = a.cand_idx[(int64_t)q * a.cap + i];
-                if ((uint32_t)r >= (uint32_t)a.N) {          // never a valid row: fail loudly (bit 4), do not fault
-                    if (a.overflow) atomicOr(a.overflow, 16);
-                    r = 0; u = -INFINITY;
-                }
-                const float strength = a.meta[(int64_t)r * 4];
-                float err = 0.5f * a.e_cos * fabsf(strength);
-                if (a.rho)
-                    err = 0.5f * fabsf(strength) * (a.rho[r] + a.e_fix + (strength < 0.0f ? 2.0f * a.eq_worst : eqq));
-                cu[j] = u; cr[j] = r; cl[j] = ord_key(u - 2.0f * err);
+        const int i = j * 64 + lane;
+        if (j < nj && i < n) {
+            cu[j] = a.cand_scores[(int64_t)q * a.cap + i];
+            cr[j] = a.cand_idx[(int64_t)q * a.cap + i];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < RW_CAND; ++j) {
+        const int i = j * 64 + lane;
+        if (j < nj && i < n) {
+            if ((uint32_t)cr[j] >= (uint32_t)a.N) {          // never a valid row: fail loudly (bit 4), do not fault
+                if (a.overflow) atomicOr(a.overflow, 16);
+                cr[j] = 0; cu[j] = -INFINITY;
             }
+            const float strength = a.meta[(int64_t)cr[j] * 4];
+            float err = 0.5f * a.e_cos * fabsf(strength);
+            if (a.rho)
+                err = 0.5f * fabsf(strength) * (a.rho[cr[j]] + a.e_fix + (strength < 0.0f ? 2.0f * a.eq_worst : eqq));
+            cl[j] = ord_key(cu[j] - 2.0f * err);
         }
     }
     // ---- T2 = k-th largest L (everything survives if n < k) ----
@@ -1191,13 +1197,10 @@ __global__ __launch_bounds__(RF_THREADS) void coarse_refine_wave_kernel(const Re
         }
     }
     if (S > RW_SURV) {
-        if (lane == 0) a.heavy[q] = 1;
+        if (lane == 0) a.heavy[1 + atomicAdd(a.heavy, 1)] = q;
         return;
     }
-    if (lane == 0) {
-        a.heavy[q] = 0;
-        if (S == 0 && a.overflow) atomicOr(a.overflow, AURA_KNN_FLAG_NO_CANDIDATES);   // (not an overflow)
-    }
+    if (lane == 0 && S == 0 && a.overflow) atomicOr(a.overflow, AURA_KNN_FLAG_NO_CANDIDATES);   // (not an overflow)
     // ---- the query, zero padded to Dpad ----
     for (int64_t i = lane; i < Dpad; i += 64) s_q[i] = i < D ? a.queries[(int64_t)q * D + i] : 0.0f;
     __builtin_amdgcn_wave_barrier();
@@ -1293,14 +1296,14 @@ __global__ __launch_bounds__(RF_THREADS) void coarse_refine_kernel(const RefineA
     __shared__ int s_ns, s_sel_k;
     __shared__ uint32_t s_prefix;
 
-    const int q = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int64_t D = a.D;
     const bool tm = a.dbg_out != nullptr;
-    if (a.heavy && a.heavy[q] == 0) {                        // finished by coarse_refine_wave_kernel
-        refine_signal_done(a, tid);
-        return;
-    }
+    // without a heavy list: one workgroup per query (blockIdx.x); with one: the grid walks the list
+    const int n_items = a.heavy ? a.heavy[0] : (int)gridDim.x;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const int q = a.heavy ? a.heavy[1 + item] : item;
     uint32_t tst[7] = {0u, 0u, 0u, 0u, 0u, 0u, 0u};
     auto stamp = [&](int i) { if (tm) tst[i] = (uint32_t)__builtin_amdgcn_s_memrealtime(); };
     stamp(0);
@@ -1481,6 +1484,8 @@ __global__ __launch_bounds__(RF_THREADS) void coarse_refine_kernel(const RefineA
             for (int i = 0; i < 6; ++i) o[i] = (float)(tst[i + 1] - tst[i]);
             o[6] = (float)n; o[7] = (float)S;
         }
+    }
+    __syncthreads();                                         // (list walk: the shared arrays are reused)
     }
     refine_signal_done(a, tid);
 }

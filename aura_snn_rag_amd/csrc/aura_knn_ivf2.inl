@@ -366,7 +366,7 @@ static Ivf2Workspace carve_ivf2(void* base, int64_t Npad, int64_t nq, int k) {
     w.gmax = reinterpret_cast<float*>(take(mb * 256 * 2 * ivf2_stiles(Npad) * 4));
     w.qhat = reinterpret_cast<uint16_t*>(take((qp + 1) * 768 * 2));   // one fragment set per query + the zero entry
     w.rowc = reinterpret_cast<float4*>(take((Npad > 0 ? Npad : 1) * 16));
-    w.heavy = reinterpret_cast<int32_t*>(take(qp * 4));
+    w.heavy = reinterpret_cast<int32_t*>(take((qp + 1) * 4));
     w.bytes = off;
     return w;
 }
