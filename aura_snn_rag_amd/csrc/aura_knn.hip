@@ -2260,13 +2260,20 @@ inline int launch_refine_for(const RefineArgs& r_in, int nqb, int64_t D, int cus
     static const int wave_mode = getenv("AURA_RF_WAVE") ? atoi(getenv("AURA_RF_WAVE")) : -1;
     const bool use_wave = heavy && !r.dbg_out && (wave_mode == 1 || (wave_mode != 0 && nqb > 2 * cus));
     if (use_wave) {
-        const size_t region = (size_t)Dpad * 4 + (size_t)RW_ROWS * (RW_KC + 4) * 4 + (size_t)RW_SURV * 12;
+        const bool big = nqb <= 8 * cus;                      // every query gets a wave at one workgroup per CU
+        const int rows_w = big ? 16 : 6;
+        const size_t region = (size_t)Dpad * 4 + (size_t)rows_w * (RW_KC + 4) * 4 + (size_t)RW_SURV * 12;
         const size_t lds_w = 8 * region;
         if (lds_w <= 150 * 1024) {
-            if (ensure_lds_attr(reinterpret_cast<const void*>(coarse_refine_wave_kernel), 150 * 1024)) return AURA_E_LAUNCH;
             r.heavy = heavy;
             if (hipMemsetAsync(heavy, 0, 4, s) != hipSuccess) return AURA_E_LAUNCH;
-            hipLaunchKernelGGL(coarse_refine_wave_kernel, dim3((unsigned)((nqb + 7) / 8)), dim3(RF_THREADS), lds_w, s, r, nqb);
+            if (big) {
+                if (ensure_lds_attr(reinterpret_cast<const void*>(coarse_refine_wave16_kernel), 150 * 1024)) return AURA_E_LAUNCH;
+                hipLaunchKernelGGL(coarse_refine_wave16_kernel, dim3((unsigned)((nqb + 7) / 8)), dim3(RF_THREADS), lds_w, s, r, nqb);
+            } else {
+                if (ensure_lds_attr(reinterpret_cast<const void*>(coarse_refine_wave6_kernel), 150 * 1024)) return AURA_E_LAUNCH;
+                hipLaunchKernelGGL(coarse_refine_wave6_kernel, dim3((unsigned)((nqb + 7) / 8)), dim3(RF_THREADS), lds_w, s, r, nqb);
+            }
             if (check_launch()) return AURA_E_LAUNCH;
         }
     }
@@ -2275,6 +2282,13 @@ inline int launch_refine_for(const RefineArgs& r_in, int nqb, int64_t D, int cus
         constexpr int ROWS = decltype(rows_tag)::value, KC = decltype(kc_tag)::value;
         size_t lds = (size_t)8 * ROWS * (KC + 4) * 4 + (size_t)Dpad * 4;
         if (lds < (size_t)RF_CAP * 12) lds = (size_t)RF_CAP * 12;
+        if (r.heavy) {
+            if (ensure_lds_attr(reinterpret_cast<const void*>(coarse_refine_list_kernel<ROWS, KC>),
+                                8 * ROWS * (KC + 4) * 4 + 768 * 4))
+                return AURA_E_LAUNCH;
+            hipLaunchKernelGGL((coarse_refine_list_kernel<ROWS, KC>), dim3((unsigned)grid_q), dim3(RF_THREADS), lds, s, r);
+            return check_launch();
+        }
         if (ensure_lds_attr(reinterpret_cast<const void*>(coarse_refine_kernel<ROWS, KC>),
                             8 * ROWS * (KC + 4) * 4 + 768 * 4))
             return AURA_E_LAUNCH;

@@ -1114,11 +1114,13 @@ __device__ __forceinline__ void refine_signal_done(const RefineArgs& a, int tid)
 // A query with more than 64 RW_CAND candidates or more than RW_SURV survivors goes on the `heavy` list and is left
 // to the kernel below, launched right after with a small grid that walks that list (usually empty).
 // ------------------------------------------------------------------------------------------
-constexpr int RW_CAND = 16;              // candidates per lane
 constexpr int RW_SURV = 128;             // survivors per query
-constexpr int RW_ROWS = 6, RW_KC = 192;  // survivors per round x k-chunk of the private stage
+constexpr int RW_KC = 192;               // k-chunk of the private stage; RW_ROWS survivors per round: 16 (one workgroup
+                                         // = 8 queries per CU: a pass of at most 8 queries per CU, where a query's
+                                         // ~60 survivors should take few rounds) or 6 (two workgroups per CU)
 
-__global__ __launch_bounds__(RF_THREADS) void coarse_refine_wave_kernel(const RefineArgs a, int nq) {
+template <int RW_ROWS, int RW_CAND>      // RW_CAND: candidates per lane (64 RW_CAND per query at most)
+__device__ __forceinline__ void refine_wave_body(const RefineArgs& a, int nq) {
     extern __shared__ __attribute__((aligned(16))) char rwmem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int q = blockIdx.x * 8 + wave;
@@ -1282,8 +1284,17 @@ __global__ __launch_bounds__(RF_THREADS) void coarse_refine_wave_kernel(const Re
     }
 }
 
+// 16 survivors per round, up to 1024 candidates: one workgroup (8 queries) per CU, up to 256 registers per lane;
+// 6 per round, up to 512 candidates: two workgroups per CU, so at most 128 registers
+__global__ __launch_bounds__(RF_THREADS) void coarse_refine_wave16_kernel(const RefineArgs a, int nq) {
+    refine_wave_body<16, 16>(a, nq);
+}
+__global__ __launch_bounds__(RF_THREADS, 4) void coarse_refine_wave6_kernel(const RefineArgs a, int nq) {
+    refine_wave_body<6, 8>(a, nq);
+}
+
 template <int RF_ROWS, int RF_KC>
-__global__ __launch_bounds__(RF_THREADS) void coarse_refine_kernel(const RefineArgs a) {
+__device__ __forceinline__ void refine_one_query(const RefineArgs& a, const int q) {
     extern __shared__ __attribute__((aligned(16))) char rsmem[];
     // phase A: candidate arrays; phase B (aliases A): per-wave row chunks + the query
     float* const s_u = reinterpret_cast<float*>(rsmem);                       // [RF_CAP]
@@ -1300,10 +1311,6 @@ __global__ __launch_bounds__(RF_THREADS) void coarse_refine_kernel(const RefineA
     const int wave = tid >> 6, lane = tid & 63;
     const int64_t D = a.D;
     const bool tm = a.dbg_out != nullptr;
-    // without a heavy list: one workgroup per query (blockIdx.x); with one: the grid walks the list
-    const int n_items = a.heavy ? a.heavy[0] : (int)gridDim.x;
-    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-    const int q = a.heavy ? a.heavy[1 + item] : item;
     uint32_t tst[7] = {0u, 0u, 0u, 0u, 0u, 0u, 0u};
     auto stamp = [&](int i) { if (tm) tst[i] = (uint32_t)__builtin_amdgcn_s_memrealtime(); };
     stamp(0);
@@ -1485,10 +1492,26 @@ __global__ __launch_bounds__(RF_THREADS) void coarse_refine_kernel(const RefineA
             o[6] = (float)n; o[7] = (float)S;
         }
     }
-    __syncthreads();                                         // (list walk: the shared arrays are reused)
-    }
-    refine_signal_done(a, tid);
 }
+
+// one workgroup per query
+template <int RF_ROWS, int RF_KC>
+__global__ __launch_bounds__(RF_THREADS) void coarse_refine_kernel(const RefineArgs a) {
+    refine_one_query<RF_ROWS, RF_KC>(a, (int)blockIdx.x);
+    refine_signal_done(a, threadIdx.x);
+}
+
+// a small grid walks the list of queries coarse_refine_wave_kernel left over (a.heavy; usually empty)
+template <int RF_ROWS, int RF_KC>
+__global__ __launch_bounds__(RF_THREADS) void coarse_refine_list_kernel(const RefineArgs a) {
+    const int n_items = a.heavy[0];
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        refine_one_query<RF_ROWS, RF_KC>(a, a.heavy[1 + item]);
+        __syncthreads();                                     // the shared arrays are reused
+    }
+    refine_signal_done(a, threadIdx.x);
+}
+
 
 inline bool coarse_eligible(const float* bank, const uint16_t* bank16, const float* queries, const float* loc_q,
                             const float* centroids, int64_t N, int64_t D, int k, int flags) {
