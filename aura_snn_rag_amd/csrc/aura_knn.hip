@@ -2258,7 +2258,9 @@ inline int launch_refine_for(const RefineArgs& r_in, int nqb, int64_t D, int cus
     // Passes of many queries: one WAVE per query first (coarse_refine_wave_kernel); the workgroup-per-query kernel
     // then only works on the queries that one marked heavy.  AURA_RF_WAVE=0 / 1: never / always (A/B runs).
     static const int wave_mode = getenv("AURA_RF_WAVE") ? atoi(getenv("AURA_RF_WAVE")) : -1;
-    const bool use_wave = heavy && !r.dbg_out && (wave_mode == 1 || (wave_mode != 0 && nqb > 2 * cus));
+    // (At 8 queries per CU the workgroup-per-query kernel is the faster one: 125 us against 136 + list walk for the
+    //  2048-query headline; beyond, its two queries per CU are the limit: 16384 queries 0.9 ms against 0.7.)
+    const bool use_wave = heavy && !r.dbg_out && (wave_mode == 1 || (wave_mode != 0 && nqb > 8 * cus));
     if (use_wave) {
         const bool big = nqb <= 8 * cus;                      // every query gets a wave at one workgroup per CU
         const int rows_w = big ? 16 : 6;
@@ -2889,7 +2891,7 @@ static int knn_search_ivf2_impl(const float* bank, const float* inv_norm, const 
         // per query: 1/||q||, bf16 fragments, eq; resets of the pass (per-list counters, qslot, the call's flag)
         hipLaunchKernelGGL(ivf2_qprep_kernel, dim3((unsigned)((nqb + 1 + 3) / 4)), dim3(256), 0, s,
                            qptr, (int64_t)nqb, D, KS, w.qhat, w.inv_q, w.eq_q, w.qslot, w.lq_cnt,
-                           qb0 == 0 ? overflow_out : nullptr, lists_flag, w.work_counter);
+                           qb0 == 0 ? overflow_out : nullptr, lists_flag);
         if ((rc = check_launch())) return rc;
         stage("query prep");
         // the probe launch also fills the per-list query lists (lq_cnt / lq_list); probes that the caller
@@ -2996,9 +2998,6 @@ static int knn_search_ivf2_impl(const float* bank, const float* inv_norm, const 
         r.rho = rho; r.eq = w.eq_q; r.e_fix = e_fix; r.eq_worst = coarse_eq_worst((float)D);
         r.cand_scores = w.cand_scores; r.cand_idx = w.cand_idx; r.cap = w.cap; r.idx_base = idx_base;
         r.out_scores = out_scores + qb0 * k; r.out_idx = out_idx + qb0 * k; r.overflow = overflow_out;
-        if (host_word && qb0 + w.qp >= nq) {                 // the call's last pass signals its completion to the host
-            r.done_counter = w.work_counter; r.host_word = host_word; r.host_seq = host_seq;
-        }
         if (trace) {                                         // candidate lists with row ids outside the bank
             (void)hipStreamSynchronize(s);
             std::vector<int32_t> hc((size_t)nqb * CNT_STRIDE), hi((size_t)nqb * w.cap);
@@ -3025,6 +3024,10 @@ static int knn_search_ivf2_impl(const float* bank, const float* inv_norm, const 
         const bool rtm2 = (cs_dbg & 128) && rtm2_left > 0;
         if (rtm2) r.dbg_out = w.gmax;
         if ((rc = launch_refine_for(r, nqb, D, cus, s, w.heavy))) return rc;
+        if (host_word && qb0 + w.qp >= nq) {                 // behind the call's last launch: flag + sequence number to the host
+            hipLaunchKernelGGL(ivf2_signal_kernel, dim3(1), dim3(64), 0, s, overflow_out, host_word, host_seq);
+            if ((rc = check_launch())) return rc;
+        }
         if (rtm2) {
             --rtm2_left;
             print_refine_phases(s, w.gmax, nqb, "inverted lists");

@@ -1076,32 +1076,9 @@ struct RefineArgs {
     int32_t* out_idx;
     int32_t* overflow;
     float* dbg_out;             // AURA_CS_DBG bit 128: [nq][8] phase times (100 MHz ticks), n, S
-    // completion word (optional): the LAST workgroup to finish publishes the call's flag and `host_seq` into
-    // host-mapped memory, so the caller learns the flag by polling two words instead of a device-to-host copy
-    // and a stream synchronisation (aura_knn_search_ivf2_signal)
     int32_t* heavy;             // optional [1 + nq]: heavy[0] = number of queries coarse_refine_wave_kernel left to the
                                 // workgroup-per-query kernel (zero before that launch), heavy[1..] = those queries
-    int32_t* done_counter;      // device, zero at launch
-    volatile uint32_t* host_word;   // host-mapped: [0] = flag, [1] = sequence number
-    uint32_t host_seq;
 };
-
-// completion word: the LAST workgroup of the launch publishes the call's flag (see RefineArgs)
-__device__ __forceinline__ void refine_signal_done(const RefineArgs& a, int tid) {
-    if (!a.host_word) return;
-    __syncthreads();                                         // this workgroup's results and flag bits are issued
-    if (tid == 0) {
-        __threadfence();                                     // ... and visible device-wide before the count
-        const int old = atomicAdd(a.done_counter, 1);
-        if (old == (int)gridDim.x - 1) {                     // every other workgroup has counted: the flag is final
-            const int f = a.overflow ? atomicAdd(a.overflow, 0) : 0;
-            a.host_word[0] = (uint32_t)f;
-            __threadfence_system();
-            a.host_word[1] = a.host_seq;
-            __threadfence_system();
-        }
-    }
-}
 
 // ------------------------------------------------------------------------------------------
 // Refine, one WAVE per query (round 3) -- for passes of many queries.  The workgroup-per-query kernel below
@@ -1498,7 +1475,6 @@ __device__ __forceinline__ void refine_one_query(const RefineArgs& a, const int 
 template <int RF_ROWS, int RF_KC>
 __global__ __launch_bounds__(RF_THREADS) void coarse_refine_kernel(const RefineArgs a) {
     refine_one_query<RF_ROWS, RF_KC>(a, (int)blockIdx.x);
-    refine_signal_done(a, threadIdx.x);
 }
 
 // a small grid walks the list of queries coarse_refine_wave_kernel left over (a.heavy; usually empty)
@@ -1509,7 +1485,6 @@ __global__ __launch_bounds__(RF_THREADS) void coarse_refine_list_kernel(const Re
         refine_one_query<RF_ROWS, RF_KC>(a, a.heavy[1 + item]);
         __syncthreads();                                     // the shared arrays are reused
     }
-    refine_signal_done(a, threadIdx.x);
 }
 
 

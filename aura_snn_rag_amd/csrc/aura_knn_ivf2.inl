@@ -139,13 +139,11 @@ __global__ __launch_bounds__(256) void ivf2_qprep_kernel(const float* __restrict
                                                          uint16_t* __restrict__ qfrag, float* __restrict__ inv,
                                                          float* __restrict__ eq_q, int32_t* __restrict__ qslot,
                                                          int32_t* __restrict__ lq_cnt, int32_t* overflow,
-                                                         const int32_t* __restrict__ lists_flag,
-                                                         int32_t* __restrict__ done_counter) {
+                                                         const int32_t* __restrict__ lists_flag) {
     const int lane = threadIdx.x & 63;
     const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (blockIdx.x == 0) {
         lq_cnt[threadIdx.x] = 0;
-        if (threadIdx.x == 0) done_counter[0] = 0;          // (the refine launch's completion count)
         // reset of the call's flag; bit 7: aura_ivf2_append dropped a row because a list had no slack left
         if (overflow && threadIdx.x == 0) *overflow = (lists_flag && *lists_flag) ? AURA_KNN_FLAG_LISTS_STALE : 0;
     }
@@ -294,6 +292,18 @@ __global__ __launch_bounds__(256) void ivf2_threshold_kernel(const float* __rest
             if (T2 < 0x00800000u) T2 = 0x00800000u;
         }
         if (lane == 0) { bounds[(int64_t)q * 2] = ord_unkey(T); bounds[(int64_t)q * 2 + 1] = ord_unkey(T2); }
+    }
+}
+
+// Completion word (aura_knn_search_ivf2_signal): launched behind the call's last kernel, so the flag is final.
+// (The first version counted finished workgroups inside the refine kernel: 2048 atomics on one address cost the
+// launch 80 us.)
+__global__ void ivf2_signal_kernel(const int32_t* __restrict__ flag, volatile uint32_t* host_word, uint32_t seq) {
+    if (threadIdx.x == 0) {
+        host_word[0] = (uint32_t)(flag ? *flag : 0);
+        __threadfence_system();
+        host_word[1] = seq;
+        __threadfence_system();
     }
 }
 

@@ -320,7 +320,7 @@ int aura_knn_search_ivf2_probed(const float* bank, const float* inv_norm, const 
 
 /* aura_knn_search_ivf2[_probed] (probe_ids may be NULL) that also tells the HOST when the call is done and what
  * its flag is, without a device-to-host copy: host_word is 64 bytes of host-mapped memory from
- * aura_host_word_alloc; the last workgroup of the call's last launch stores the flag into host_word[0] and then
+ * aura_host_word_alloc; a one-thread launch behind the call's last kernel stores the flag into host_word[0] and then
  * host_seq into host_word[1].  The caller polls host_word[1] == host_seq (choose a new host_seq per call) and reads
  * the flag from host_word[0]; results are then final on the stream as after any launch.  One call in flight per
  * host_word.  (The flag read costs the reference-style caller a stream synchronisation per recall otherwise:
