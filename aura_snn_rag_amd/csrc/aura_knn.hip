@@ -2260,7 +2260,10 @@ inline int launch_refine_for(const RefineArgs& r_in, int nqb, int64_t D, int cus
     static const int wave_mode = getenv("AURA_RF_WAVE") ? atoi(getenv("AURA_RF_WAVE")) : -1;
     // (At 8 queries per CU the workgroup-per-query kernel is the faster one: 125 us against 136 + list walk for the
     //  2048-query headline; beyond, its two queries per CU are the limit: 16384 queries 0.9 ms against 0.7.)
-    const bool use_wave = heavy && !r.dbg_out && (wave_mode == 1 || (wave_mode != 0 && nqb > 8 * cus));
+    // Beyond 8 queries per CU the one-wave form pays where most queries keep at most 512 candidates -- the shards of a
+    // row-sharded bank (125 000 rows x 16 384 queries: 1.59 against 1.75 ms per recall); on a 1 M-row bank a query
+    // keeps ~560, half of them overflow to the list and both kernels run (16 384 queries: 3.9 against 3.1 ms).
+    const bool use_wave = heavy && !r.dbg_out && (wave_mode == 1 || (wave_mode != 0 && nqb > 8 * cus && r.N <= 300000));
     if (use_wave) {
         const bool big = nqb <= 8 * cus;                      // every query gets a wave at one workgroup per CU
         const int rows_w = big ? 16 : 6;
