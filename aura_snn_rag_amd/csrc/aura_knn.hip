@@ -2863,6 +2863,9 @@ static int knn_search_ivf2_impl(const float* bank, const float* inv_norm, const 
     };
     const int stiles = ivf2_stiles(n_sorted);                // sample tiles per list
     static const bool w4 = getenv("AURA_CS_WAVES4") != nullptr;   // A/B runs: one wave per SIMD
+    // AURA_IVF_WG4: TWO independent four-wave workgroups per CU, 128 query slots per block (round-3 experiment)
+    static const bool wg4 = !w4 && getenv("AURA_IVF_WG4") != nullptr;
+    const int bsh = wg4 ? 7 : 8;
     // Relative time of a filter tile in a block of <= 128 queries and in a fuller one (the one- and the
     // two-column-block form of the tile loop): the plan splits tiles x weight evenly over the workgroups.
     // AURA_IVF_W=s,d overrides (tuning runs); the one-wave-per-SIMD form has a single tile loop.
@@ -2870,7 +2873,7 @@ static int knn_search_ivf2_impl(const float* bank, const float* inv_norm, const 
     if (w_sparse == 0) {
         int ws = 5, wd = 7;
         if (const char* e = getenv("AURA_IVF_W")) { if (sscanf(e, "%d,%d", &ws, &wd) != 2 || ws < 1 || wd < 1 || ws > 64 || wd > 64) { ws = 5; wd = 7; } }
-        if (w4) ws = wd = 1;
+        if (w4 || wg4) ws = wd = 1;
         w_dense = wd; w_sparse = ws;
     }
     // The sorted rows' score constants depend on `now` and the bank only: the caller may keep them across
@@ -2908,12 +2911,13 @@ static int knn_search_ivf2_impl(const float* bank, const float* inv_norm, const 
         stage("probe");
         hipLaunchKernelGGL(ivf2_plan_kernel, dim3(1), dim3(256), 0, s, w.lq_cnt, pad_off, list_len, w.blk_off,
                            w.blk_list, w.blk_row0, w.blk_stride, w.blk_nq, w.item_off, w.sitem_off, w.nblk,
-                           stiles, w_sparse, w_dense);
+                           stiles, w_sparse, w_dense, bsh);
         if ((rc = check_launch())) return rc;
         stage("plan");
-        hipLaunchKernelGGL(ivf2_slots_kernel, dim3((unsigned)ivf2_maxblk(w.qp)), dim3(256), 0, s,
+        const int nslot_blocks = (int)((((int64_t)ivf2_maxblk(w.qp, bsh) << bsh) + 255) / 256);   // 256 slots per launch block
+        hipLaunchKernelGGL(ivf2_slots_kernel, dim3((unsigned)nslot_blocks), dim3(256), 0, s,
                            w.lq_cnt, w.lq_list, w.blk_off, w.blk_list, w.nblk, w.eq_q, w.slotq, w.qslot, w.thr,
-                           w.eq_slot);
+                           w.eq_slot, bsh);
         if ((rc = check_launch())) return rc;
         stage("slots");
         }
@@ -2921,7 +2925,7 @@ static int knn_search_ivf2_impl(const float* bank, const float* inv_norm, const 
         CoarseArgs c{};
         c.bank = bank; c.bank16 = sorted_bf16; c.rowc = rowc; c.qhat = w.qhat; c.inv_q = w.inv_q;
         c.eq = w.eq_slot; c.qzero = nqb;
-        c.N = n_sorted; c.D = D; c.nq = ivf2_maxblk(w.qp) * 256;
+        c.N = n_sorted; c.D = D; c.nq = ivf2_maxblk(w.qp, bsh) << bsh;
         c.thr = w.thr; c.cnt = w.cnt; c.cand_scores = w.cand_scores; c.cand_idx = w.cand_idx; c.cap = w.cap;
         c.blk_row0 = w.blk_row0; c.blk_stride = w.blk_stride; c.nblk = w.nblk; c.slotq = w.slotq;
         c.blk_nq = w.blk_nq; c.w_sparse = w_sparse; c.w_dense = w_dense;
@@ -2929,6 +2933,11 @@ static int knn_search_ivf2_impl(const float* bank, const float* inv_norm, const 
         static const int cs_dbg = getenv("AURA_CS_DBG") ? atoi(getenv("AURA_CS_DBG")) : 0;
         c.dbg = cs_dbg;
         auto launch = [&](int mode) -> int {
+            if (wg4) {
+                if (KS == 8) return launch_coarse_ivf<8, 4, 2>(c, mode, 2 * cus, s);
+                if (KS == 16) return launch_coarse_ivf<16, 4, 2>(c, mode, 2 * cus, s);
+                return launch_coarse_ivf<24, 4, 2>(c, mode, 2 * cus, s);
+            }
             if (w4) {
                 if (KS == 8) return launch_coarse_ivf<8, 4>(c, mode, cus, s);
                 if (KS == 16) return launch_coarse_ivf<16, 4>(c, mode, cus, s);
@@ -2944,7 +2953,7 @@ static int knn_search_ivf2_impl(const float* bank, const float* inv_norm, const 
         {
             const dim3 tg((unsigned)((nqb + 3) / 4)), tb(256);
 #define AURA_THR2(PER) hipLaunchKernelGGL((ivf2_threshold_kernel<PER>), tg, tb, 0, s, w.gmax, w.qslot, w.blk_list, list_len, \
-                                          nprobe, k, nqb, w.thr, w.cnt, stg == 1 ? k2 : 0, stg == 1 ? bounds : nullptr)
+                                          nprobe, k, nqb, w.thr, w.cnt, stg == 1 ? k2 : 0, stg == 1 ? bounds : nullptr, bsh)
             if (stiles == 32) AURA_THR2(8);
             else if (stiles == 64) AURA_THR2(16);
             else if (stiles == 128) AURA_THR2(32);
@@ -2956,8 +2965,8 @@ static int knn_search_ivf2_impl(const float* bank, const float* inv_norm, const 
         if (stg == 1) return AURA_OK;
         } else {
             // the caller's bound (e.g. combined over the shards of a row-sharded bank) tightens the thresholds
-            hipLaunchKernelGGL(ivf2_raise_thr_kernel, dim3((unsigned)ivf2_maxblk(w.qp)), dim3(256), 0, s,
-                               w.slotq, w.nblk, bounds, w.thr);
+            hipLaunchKernelGGL(ivf2_raise_thr_kernel, dim3((unsigned)((((int64_t)ivf2_maxblk(w.qp, bsh) << bsh) + 255) / 256)), dim3(256), 0, s,
+                               w.slotq, w.nblk, bounds, w.thr, bsh);
             if ((rc = check_launch())) return rc;
             stage("raise thresholds");
         }

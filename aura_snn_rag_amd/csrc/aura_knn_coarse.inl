@@ -56,7 +56,7 @@ constexpr int CS_THREADS = 256;           // 4 waves (one per SIMD, 512 register
 constexpr int CS_QB = 4;                 // 16-query MFMA column blocks per wave
 constexpr int CS_ROWS = 16;              // bank rows per tile
 constexpr int CS_SLOTS = 3;
-constexpr int IVF2_MAXBLK_C = 512;       // = IVF2_MAXBLK (aura_knn_ivf2.inl; checked there): blocks of one inverted-list pass at most
+constexpr int IVF2_MAXBLK_C = 1024;      // >= IVF2_MAXBLK (aura_knn_ivf2.inl; checked there): blocks of one inverted-list pass at most
 // bf16-row 8-wave kernels (not the probe-mask form, whose masks need the LDS) allocate twice the ring:
 // their row-split form (blocks of at most 128 queries) streams two 16-row tiles per step
 template <bool SRC16, bool MASKED, int NW> constexpr int cs_lds_slots() { return (SRC16 && NW == 8 && !MASKED) ? 2 * CS_SLOTS : CS_SLOTS; }
@@ -427,15 +427,23 @@ __global__ __launch_bounds__(256) void coarse_threshold_kernel(const float* __re
 // IVF = inverted-list mode (see CoarseArgs): same scan, the work items are (block, tile) pairs.
 // NW = waves per workgroup: 4 (one per SIMD, 64 queries and 512 registers each) or, bf16 rows only,
 // 8 (two per SIMD, 32 queries and 256 registers each: the second wave fills the first one's stalls).
-template <int KS, int MODE, bool SRC16, bool MASKED, bool IVF = false, int NW = 4>
-__global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a) {
+// QBT = 16-query column blocks per wave.  NW = 4 with QBT = 2 (round 3, inverted lists only): a workgroup of four
+// waves holds 128 query slots in 256 registers per wave and half the LDS -- TWO independent workgroups per CU, so
+// that one's MFMA phase overlaps the other's wait / issue / epilogue without a barrier between them.
+template <int NW, int QBT> constexpr int cs_min_waves() { return (NW == 4 && QBT == 2) ? 2 : 1; }
+template <int NW, int QBT> constexpr int cs_cand_buf() { return (NW == 4 && QBT == 2) ? 512 : CS_BUF; }
+template <int KS, int MODE, bool SRC16, bool MASKED, bool IVF = false, int NW = 4, int QBT = 16 / NW>
+__global__ __launch_bounds__(64 * NW, (cs_min_waves<NW, QBT>())) void coarse_scan_kernel(const CoarseArgs a) {
     static_assert(!MASKED || SRC16, "the probe masks need the LDS the bf16 rows leave free");
     static_assert(!IVF || (SRC16 && !MASKED), "inverted lists run over the sorted bf16 shadow");
     static_assert(NW == 4 || (NW == 8 && SRC16), "8 waves: bf16 rows only");
     static_assert(KS % NW == 0, "pieces are dealt over the waves");
     constexpr int THREADS = 64 * NW;
-    constexpr int QB = 16 / NW;                            // 16-query MFMA column blocks per wave
-    constexpr int QA = NW == 4 ? CS_QA : CS_QA8;           // fragments pinned in AGPRs
+    constexpr int QB = QBT;                                // 16-query MFMA column blocks per wave
+    constexpr int BLKQ = NW * 16 * QB;                     // query slots per block (256; 128 in the two-workgroup form)
+    static_assert(BLKQ == 256 || (IVF && BLKQ == 128), "a query block is 256 slots (128: inverted lists, NW = 4, QBT = 2)");
+    constexpr int CBUF = cs_cand_buf<NW, QBT>();           // candidate entries buffered per workgroup
+    constexpr int QA = QB == 4 ? CS_QA : CS_QA8;           // fragments pinned in AGPRs
     constexpr int STEP_BYTES = SRC16 ? 1024 : 2048;        // one k-step (32 k) of 16 rows
     constexpr int TILE_BYTES = KS * STEP_BYTES;
     constexpr int SLOT_BYTES = TILE_BYTES + CS_AUX_BYTES;
@@ -528,16 +536,16 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
     // the halves' fill counts in scalar registers -- no LDS atomics, no shared counters, no cross-wave
     // ordering.  Tile t appends to half t&1; the other half is stable during tile t and is written out
     // (by its own wave) once it holds WFLUSH entries; entries beyond WCAP go straight to the lists.
-    constexpr int WCAP = CS_BUF / (2 * NW);                // 64 (8 waves) or 128 (4 waves)
+    constexpr int WCAP = CBUF / (2 * NW);                  // 64 (8 waves; 4 waves x 32 queries) or 128 (4 waves x 64 queries)
     constexpr int EPL = WCAP / 64;                         // entries per lane and half in a write-out
     constexpr int WFLUSH = WCAP / CS_WFLUSH_DIV;
     const uint32_t cs_base = lds_addr(csmem);
     const uint32_t buf_addr = cs_base + LSLOTS * SLOT_BYTES;
     const uint32_t wreg_addr = buf_addr + wave * (2 * WCAP * 12);
-    const uint32_t mask_addr = buf_addr + CS_BUF * 12;            // [256][8] probe masks (MASKED) / [256] slot -> query (IVF)
+    const uint32_t mask_addr = buf_addr + CBUF * 12;              // [256][8] probe masks (MASKED) / [BLKQ] slot -> query (IVF)
     // [256] query parts of the error bound (SRC16), signed for the mode: kept in LDS, not in registers --
     // two more live VGPRs across the tile loop made the 24-k-step 8-wave kernels spill inside it
-    constexpr int EQ_OFF = CS_BUF * 12 + (MASKED ? 256 * 32 : (IVF ? 256 * 4 : 0));
+    constexpr int EQ_OFF = CBUF * 12 + (MASKED ? 256 * 32 : (IVF ? BLKQ * 4 : 0));
     const uint32_t eq_addr = buf_addr + EQ_OFF;
     int wc[2] = {0, 0};                                    // fill counts of this wave's halves (wave-uniform)
     // span-end write-out of both halves: every slot reservation is issued before any is waited for
@@ -629,7 +637,7 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
         constexpr int TPS = RS == 1 ? 1 : 2;                // tiles per step
         const int qg = SPLIT ? (wave & 3) : wave;           // query group: slots [qg * 16 QB, + 16 QB) of the block
         const int rh = SPLIT ? (wave >> 2) : 0;             // row-split: which tile of the step this wave works on
-        const int qoff = (int)qblk * 256 + qg * (16 * QB);  // this wave's first query (IVF: block slot)
+        const int qoff = (int)qblk * BLKQ + qg * (16 * QB); // this wave's first query (IVF: block slot)
         int my_cnt = n_used - qg * (16 * QB);
         my_cnt = my_cnt < 0 ? 0 : (my_cnt > 16 * NBc ? 16 * NBc : my_cnt);
         // column blocks this wave runs (wave-uniform, in a scalar register)
@@ -642,7 +650,7 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
         float thrf[NBc];
         int qid[NBc];                                       // IVF filter: the queries in this lane's slots (16 b + lr)
         if (MASKED) {                                       // this block's probe masks -> LDS
-            uint32_t* const s_mask = reinterpret_cast<uint32_t*>(csmem + LSLOTS * SLOT_BYTES + CS_BUF * 12);
+            uint32_t* const s_mask = reinterpret_cast<uint32_t*>(csmem + LSLOTS * SLOT_BYTES + CBUF * 12);
             for (int i = tid; i < 256 * 8; i += THREADS) {
                 const int64_t q = qblk * 256 + (i >> 3);
                 s_mask[i] = q < a.nq ? a.probe_mask[q * 8 + (i & 7)] : 0u;
@@ -652,8 +660,8 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
         // query part of the error bound: the accumulators start at +eq (FILTER: U) / -eq (SAMPLE: L)
         if (SRC16) {
             float* const s_eq = reinterpret_cast<float*>(csmem + LSLOTS * SLOT_BYTES + EQ_OFF);
-            if (tid < 256) {
-                const int64_t q = qblk * 256 + tid;
+            if (tid < BLKQ) {
+                const int64_t q = qblk * BLKQ + tid;
                 const float v = a.eq[q < a.nq ? q : a.nq - 1];
                 s_eq[tid] = MODE == CS_MODE_FILTER ? v : -v;
             }
@@ -801,7 +809,7 @@ __global__ __launch_bounds__(64 * NW) void coarse_scan_kernel(const CoarseArgs a
             // fragment reads run two k-steps ahead of the MFMAs (one wave per SIMD: nothing else
             // hides the LDS latency)
             // k-steps the reads run ahead (8 waves: registers are short, the other wave hides the latency)
-            constexpr int PF = (SRC16 && NW == 4) ? CS_PF16 : 2;
+            constexpr int PF = (SRC16 && NW == 4 && QB == 4) ? CS_PF16 : 2;
             f32x4v xr[PF + 1][2];
             constexpr int RP = SRC16 ? 1 : 2;                // LDS reads per k-step
             constexpr int S_RC = KS >= 3 ? KS - 3 : 0;       // the row constants are fetched behind this step

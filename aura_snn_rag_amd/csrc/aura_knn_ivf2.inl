@@ -39,10 +39,11 @@ constexpr int IVF2_MAXQ = 8192;            // queries per pass: every probed lis
                                            // queries that probe it, so large batches (bulk recall, the all-gathered
                                            // query blocks of a sharded bank) want long passes; workspace grows with
                                            // min(nq, IVF2_MAXQ) (2048 queries: as in r01)
-// blocks of a pass of qp queries at most: sum over the lists of ceil(count / 256) <= 256 + 8 qp / 256
-static inline int ivf2_maxblk(int64_t qp) { return 256 + (int)((qp * 8 + 255) / 256); }
-constexpr int IVF2_MAXBLK = 256 + IVF2_MAXQ * 8 / 256;
-static_assert(IVF2_MAXBLK == IVF2_MAXBLK_C, "coarse_scan_kernel's block search covers IVF2_MAXBLK_C prefixes");
+// A block holds 1 << bsh query slots: 256, or 128 in the two-workgroups-per-CU form of the scan (AURA_IVF_WG4).
+// Blocks of a pass of qp queries at most: sum over the lists of ceil(count / B) <= 256 + 8 qp / B.
+static inline int ivf2_maxblk(int64_t qp, int bsh = 8) { return 256 + (int)((qp * 8 + (1 << bsh) - 1) >> bsh); }
+constexpr int IVF2_MAXBLK = 256 + IVF2_MAXQ * 8 / 128;
+static_assert(IVF2_MAXBLK <= IVF2_MAXBLK_C, "coarse_scan_kernel's block search covers IVF2_MAXBLK_C prefixes");
 
 // queries probing list c: the per-list query list holds IVF2_MAXQ entries, a counter beyond that (caller-made
 // probe ids that repeat a list) is clamped everywhere it is read
@@ -64,11 +65,13 @@ __global__ __launch_bounds__(256) void ivf2_plan_kernel(const int32_t* __restric
                                                         int32_t* sitem_off,  // [MAXBLK + 1] sample items
                                                         int32_t* nblk,
                                                         int stiles,          // sample tiles per list (ivf2_stiles)
-                                                        int w_sparse, int w_dense) {   // cost of a tile of a block of <= 128 / more queries
+                                                        int w_sparse, int w_dense,     // cost of a tile of a block of <= 128 / more queries
+                                                        int bsh) {           // log2 of the query slots per block (8 or 7)
     __shared__ int s_nb[257];
     const int tid = threadIdx.x;
     const int my_cnt = ivf2_list_queries(lq_cnt, tid);
-    s_nb[tid + 1] = (my_cnt + 255) / 256;
+    const int BQ = 1 << bsh;
+    s_nb[tid + 1] = (my_cnt + BQ - 1) >> bsh;
     if (tid == 0) s_nb[0] = 0;
     __syncthreads();
     for (int off = 1; off < 256; off <<= 1) {              // inclusive scan of s_nb[1..256]
@@ -83,8 +86,8 @@ __global__ __launch_bounds__(256) void ivf2_plan_kernel(const int32_t* __restric
     for (int b = s_nb[tid]; b < s_nb[tid + 1]; ++b) {
         blk_list[b] = tid;
         blk_row0[b] = pad_off[tid];
-        const int left = my_cnt - (b - s_nb[tid]) * 256;
-        blk_nq[b] = left < 256 ? left : 256;
+        const int left = my_cnt - (b - s_nb[tid]) * BQ;
+        blk_nq[b] = left < BQ ? left : BQ;
         blk_stride[b] = tiles > stiles ? tiles / stiles : 1;   // sample tiles j * stride, j < stiles
     }
     __syncthreads();
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(256) void ivf2_plan_kernel(const int32_t* __restric
     __shared__ int s_it[257], s_st[257];
     const int nb = s_nb[tid + 1] - s_nb[tid];
     const int stl = tiles < stiles ? tiles : stiles;
-    const int last_left = my_cnt - (nb - 1) * 256;
+    const int last_left = my_cnt - (nb - 1) * BQ;
     const int w_last = last_left <= 128 ? w_sparse : w_dense;
     s_it[tid + 1] = nb > 0 ? tiles * ((nb - 1) * w_dense + w_last) : 0; s_st[tid + 1] = nb * stl;
     if (tid == 0) { s_it[0] = 0; s_st[0] = 0; }
@@ -198,12 +201,12 @@ __global__ __launch_bounds__(256) void ivf2_slots_kernel(const int32_t* __restri
                                                          const int32_t* __restrict__ nblk,
                                                          const float* __restrict__ eq_q,
                                                          int32_t* __restrict__ slotq, int32_t* __restrict__ qslot,
-                                                         uint32_t* __restrict__ thr, float* __restrict__ eq_slot) {
-    const int64_t vs = (int64_t)blockIdx.x * 256 + threadIdx.x;            // virtual slot = B * 256 + slot
-    const int B = (int)(vs >> 8);
+                                                         uint32_t* __restrict__ thr, float* __restrict__ eq_slot, int bsh) {
+    const int64_t vs = (int64_t)blockIdx.x * 256 + threadIdx.x;            // virtual slot = (B << bsh) + slot
+    const int B = (int)(vs >> bsh);
     if (B >= nblk[0]) return;
     const int list = blk_list[B];
-    const int ls = (B - blk_off[list]) * 256 + (int)(vs & 255);           // slot inside the list's query list
+    const int ls = ((B - blk_off[list]) << bsh) + (int)(vs & ((1 << bsh) - 1));   // slot inside the list's query list
     int q = -1, p = 0;
     if (ls < ivf2_list_queries(lq_cnt, list)) {
         const int packed = lq_list[(int64_t)list * IVF2_MAXQ + ls];
@@ -239,7 +242,8 @@ __global__ __launch_bounds__(256) void ivf2_threshold_kernel(const float* __rest
                                                              int nprobe, int k, int nq,
                                                              uint32_t* __restrict__ thr,
                                                              int32_t* __restrict__ cnt_out,
-                                                             int k2, float* __restrict__ bounds) {   // staged recall: bounds[q] = {T_k, T_k2}
+                                                             int k2, float* __restrict__ bounds,     // staged recall: bounds[q] = {T_k, T_k2}
+                                                             int bsh) {
     const int lane = threadIdx.x & 63;
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= nq) return;
@@ -252,7 +256,7 @@ __global__ __launch_bounds__(256) void ivf2_threshold_kernel(const float* __rest
     int vs = -1;
     if (p < nprobe) vs = qslot[(int64_t)q * 8 + p];       // -1: the probe was dropped (id out of range / repeated)
     if (vs >= 0) {
-        const int list = blk_list[vs >> 8];
+        const int list = blk_list[vs >> bsh];
         const int tiles = (list_len[list] + 15) / 16;
         const int groups = 2 * (tiles < STL ? tiles : STL);
 #pragma unroll
@@ -311,9 +315,9 @@ __global__ void ivf2_signal_kernel(const int32_t* __restrict__ flag, volatile ui
 __global__ __launch_bounds__(256) void ivf2_raise_thr_kernel(const int32_t* __restrict__ slotq,
                                                              const int32_t* __restrict__ nblk,
                                                              const float* __restrict__ bound_q,
-                                                             uint32_t* __restrict__ thr) {
+                                                             uint32_t* __restrict__ thr, int bsh) {
     const int64_t vs = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if ((int)(vs >> 8) >= nblk[0]) return;
+    if ((int)(vs >> bsh) >= nblk[0]) return;
     const int q = slotq[vs];
     if (q < 0) return;
     const float b = bound_q[q];
@@ -346,7 +350,8 @@ static Ivf2Workspace carve_ivf2(void* base, int64_t Npad, int64_t nq, int k) {
     };
     int64_t qp = nq < IVF2_MAXQ ? (nq > 0 ? nq : 1) : IVF2_MAXQ;
     w.qp = (int)qp;
-    const int64_t mb = ivf2_maxblk(qp);                    // blocks, and mb * 256 query slots
+    const int64_t mb = ivf2_maxblk(qp, 8);                 // mb * 256 query slots (the most either block size needs)
+    const int64_t mbb = ivf2_maxblk(qp, 7);                // blocks (the most either block size needs)
     w.cap = RF_CAP;                                         // refine holds at most this many per query
     w.inv_q = reinterpret_cast<float*>(take(qp * 4));
     w.probe = reinterpret_cast<uint32_t*>(take(qp * 32));
@@ -361,12 +366,12 @@ static Ivf2Workspace carve_ivf2(void* base, int64_t Npad, int64_t nq, int k) {
     w.cand_scores = reinterpret_cast<float*>(take(qp * w.cap * 4));
     w.cand_idx = reinterpret_cast<int32_t*>(take(qp * w.cap * 4));
     w.blk_off = reinterpret_cast<int32_t*>(take(257 * 4));
-    w.blk_list = reinterpret_cast<int32_t*>(take(mb * 4));
-    w.blk_row0 = reinterpret_cast<int32_t*>(take(mb * 4));
-    w.blk_stride = reinterpret_cast<int32_t*>(take(mb * 4));
-    w.blk_nq = reinterpret_cast<int32_t*>(take(mb * 4));
-    w.item_off = reinterpret_cast<int32_t*>(take((mb + 1) * 4));
-    w.sitem_off = reinterpret_cast<int32_t*>(take((mb + 1) * 4));
+    w.blk_list = reinterpret_cast<int32_t*>(take(mbb * 4));
+    w.blk_row0 = reinterpret_cast<int32_t*>(take(mbb * 4));
+    w.blk_stride = reinterpret_cast<int32_t*>(take(mbb * 4));
+    w.blk_nq = reinterpret_cast<int32_t*>(take(mbb * 4));
+    w.item_off = reinterpret_cast<int32_t*>(take((mbb + 1) * 4));
+    w.sitem_off = reinterpret_cast<int32_t*>(take((mbb + 1) * 4));
     w.nblk = reinterpret_cast<int32_t*>(take(256));
     w.slotq = reinterpret_cast<int32_t*>(take(mb * 256 * 4));
     w.qslot = reinterpret_cast<int32_t*>(take(qp * 8 * 4));
@@ -381,15 +386,17 @@ static Ivf2Workspace carve_ivf2(void* base, int64_t Npad, int64_t nq, int k) {
     return w;
 }
 
-template <int KS, int NW>
+template <int KS, int NW, int QBT = 16 / NW>
 inline int launch_coarse_ivf(const CoarseArgs& a, int mode, int grid, hipStream_t s) {
-    const size_t lds = (size_t)cs_lds_slots<true, false, NW>() * (KS * 1024 + CS_AUX_BYTES) + (size_t)CS_BUF * 12 + 256 * 4 + 256 * 4;
-    if (ensure_lds_attr(reinterpret_cast<const void*>(coarse_scan_kernel<KS, CS_MODE_SAMPLE, true, false, true, NW>), (int)lds) ||
-        ensure_lds_attr(reinterpret_cast<const void*>(coarse_scan_kernel<KS, CS_MODE_FILTER, true, false, true, NW>), (int)lds))
+    constexpr int BLKQ = NW * 16 * QBT;
+    const size_t lds = (size_t)cs_lds_slots<true, false, NW>() * (KS * 1024 + CS_AUX_BYTES) + (size_t)cs_cand_buf<NW, QBT>() * 12 +
+                       BLKQ * 4 + BLKQ * 4;
+    if (ensure_lds_attr(reinterpret_cast<const void*>(coarse_scan_kernel<KS, CS_MODE_SAMPLE, true, false, true, NW, QBT>), (int)lds) ||
+        ensure_lds_attr(reinterpret_cast<const void*>(coarse_scan_kernel<KS, CS_MODE_FILTER, true, false, true, NW, QBT>), (int)lds))
         return AURA_E_LAUNCH;
     if (mode == CS_MODE_SAMPLE)
-        hipLaunchKernelGGL((coarse_scan_kernel<KS, CS_MODE_SAMPLE, true, false, true, NW>), dim3(grid), dim3(64 * NW), lds, s, a);
+        hipLaunchKernelGGL((coarse_scan_kernel<KS, CS_MODE_SAMPLE, true, false, true, NW, QBT>), dim3(grid), dim3(64 * NW), lds, s, a);
     else
-        hipLaunchKernelGGL((coarse_scan_kernel<KS, CS_MODE_FILTER, true, false, true, NW>), dim3(grid), dim3(64 * NW), lds, s, a);
+        hipLaunchKernelGGL((coarse_scan_kernel<KS, CS_MODE_FILTER, true, false, true, NW, QBT>), dim3(grid), dim3(64 * NW), lds, s, a);
     return check_launch();
 }
