@@ -752,7 +752,9 @@ __global__ __launch_bounds__(64 * NW, (cs_min_waves<NW, QBT>())) void coarse_sca
             int fl_n = 0, fl_pos0 = 0, fl_pos1 = 0;
             if (MODE == CS_MODE_FILTER) {
                 const int nbo = wc[par ^ 1];                 // (wave-uniform, in scalar registers)
-                if (nbo >= WFLUSH) {
+                if (nbo >= WFLUSH && (a.dbg & 2048)) {       // timing experiment: drop the half instead of writing it out
+                    wc[par ^ 1] = 0;
+                } else if (nbo >= WFLUSH) {
                     fl_n = nbo < WCAP ? nbo : WCAP;
                     const uint32_t eb = wreg_addr + (par ^ 1) * (WCAP * 12);
                     if (lane < fl_n)
