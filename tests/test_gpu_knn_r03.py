@@ -72,3 +72,40 @@ def test_centroid_probe_ids_against_float64(dev, D, nq, kc):
     assert bad == 0, f"{bad} probe positions differ beyond an fp32 near-tie"
     assert bool((ids >= 0).all()) and bool((ids < 256).all())
     assert all(len(set(r.tolist())) == 8 for r in ids)
+
+
+def test_two_workgroups_per_cu_form_of_the_inverted_list_scan(dev, tmp_path):
+    """AURA_IVF_WG4=1 (read once per process: run in a child): the inverted-list scan as two independent four-wave
+    workgroups per CU over 128-slot blocks returns the rows and score bits of the fp32 masked scan."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, torch
+sys.path.insert(0, %r)
+from aura_snn_rag_amd import ops
+from aura_snn_rag_amd.core.hippocampal import HippocampalFormation
+dev = torch.device("cuda")
+for D, N, nq, k in ((64, 40000, 900, 9), (768, 30000, 2100, 32), (200, 20000, 70, 5)):
+    g = torch.Generator().manual_seed(D + nq)
+    centres = torch.randn(120, D, generator=g) * 2
+    feats = centres[torch.randint(0, 120, (N,), generator=g)] + torch.randn(N, D, generator=g)
+    q = (centres[torch.randint(0, 120, (nq,), generator=g)] + torch.randn(nq, D, generator=g)).to(dev).contiguous()
+    hf = HippocampalFormation(feature_dim=D, max_memories=N, n_place_cells=8, n_time_cells=4, n_grid_cells=4,
+                              device="cuda", use_centroid_index=True)
+    hf.bulk_write(feats.to(dev), rebuild=False)
+    hf.rebuild_centroids(perm=torch.randperm(N, generator=g))
+    now = float(hf.memory_metadata[0, 1].item())
+    ivf = hf._ensure_ivf()
+    s2, r2, ovf = ops.knn_search_ivf2(hf.memory_features, hf._inv_norm, hf.memory_metadata, q, k, now, hf.centroids, 8,
+                                      ivf.sorted_bf16, hf._rho, ivf.sorted_rows, ivf.pad_off, ivf.list_len,
+                                      n_sorted=ivf.n_sorted, lists_flag=ivf.flag)
+    assert (int(ovf.item()) & ~ops.KNN_FLAG_NO_CANDIDATES) == 0
+    s_m, r_m = ops.knn_search(hf.memory_features, hf._inv_norm, hf.memory_metadata, q, k, now, count=N,
+                              centroids=hf.centroids, nprobe=8, fp32_scan=True)
+    assert torch.equal(r2, r_m) and torch.equal(s2, s_m), (D, N, nq, k)
+print("WG4 OK")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, AURA_IVF_WG4="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "WG4 OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
