@@ -24,10 +24,13 @@ from .. import ops
 
 
 def _no_grad_input(x: torch.Tensor, who: str) -> None:
-    if x.requires_grad and torch.is_grad_enabled():
-        raise NotImplementedError(
-            f"{who}: this HIP loop does not record autograd history; call it under "
-            f"torch.no_grad() or detach the input.")
+    """Izhikevich / AdEx: the reference's spikes are ``(v >= v_peak).to(dtype)`` (``neuron.py:191``, ``:243``) -- a
+    comparison: they carry NO autograd history whatever the input requires, so a loss on them sends nothing back
+    through these loops in the reference either.  The HIP loop returns the same (history-free) spikes.  What the
+    reference has and this does not: history on the CARRIED STATE ``v / u / w`` (nothing on the path
+    backpropagates through it; the state tensors here are plain buffers).  (The LIF path with its learnable
+    surrogate records history itself and never comes here with a tensor that requires grad.)"""
+    return None
 
 
 def _as_f32_input(x: torch.Tensor, who: str) -> torch.Tensor:

@@ -279,3 +279,26 @@ def test_brain_zone_and_processor(dev):
         if hasattr(g.core, "reset_mem"): g.core.reset_mem()
     y = proc.process(x.to(dev), zone_weights={"z": 1.0})
     assert torch.allclose(y.cpu(), ref, rtol=1e-5, atol=1e-4)
+
+
+def test_izhikevich_and_adex_accept_inputs_that_require_grad(dev):
+    """The reference's spikes are a comparison ((v >= 30).to(dtype), neuron.py:191 / :243): no autograd history,
+    whatever the input requires.  The HIP loops therefore take such inputs (round 2 raised NotImplementedError)
+    and return the same history-free spikes."""
+    from aura_snn_rag_amd.base.neuron import AdExNeuron, IzhikevichNeuron
+    g = torch.Generator().manual_seed(4)
+    I = (20 * torch.rand(40, 64, generator=g)).to(dev).requires_grad_(True)
+    izh = IzhikevichNeuron(0.02, 0.2, -65.0, 8.0, 0.2).to(dev)
+    s = izh(I)
+    assert not s.requires_grad
+    rs, _, _ = _izh_oracle(I.detach().cpu())
+    assert torch.equal(s.cpu(), rs)
+    # the reference on the CPU: same property
+    from oracle import aura_oracle as OO
+    Ic = I.detach().cpu().requires_grad_(True)
+    v0, u0 = OO.izh_initial_state(40, 0.2)
+    rs2, _, _ = OO.izh_run(Ic, v0, u0, 0.02, 0.2, -65.0, 8.0, 0.2)
+    assert not rs2.requires_grad
+    ad = AdExNeuron(a=2.0, b=60.0).to(dev)
+    s2 = ad((600 * torch.rand(16, 32, generator=g)).to(dev).requires_grad_(True))
+    assert not s2.requires_grad and s2.shape == (16, 32)
