@@ -1328,31 +1328,10 @@ __device__ __forceinline__ void refine_one_query(const RefineArgs& a, const int 
     __syncthreads();
     stamp(1);
 
-    // ---- T2 = k-th largest L (everything survives if n < k).  Up to 1024 candidates -- the usual ~560 -- one wave
-    //      finds it by a 32-step ballot search with the keys in registers: no barrier, 2 us (round 3).  The 8-bit
-    //      radix select it replaces there (four passes of histogram, suffix scan and pick: 16 barriers, 5 us) stays
-    //      for longer lists ----
+    // ---- T2 = k-th largest L: MSB-first 8-bit radix select, the digit found by a parallel suffix
+    //      scan of the 256-bin histogram; everything survives if n < k ----
     uint32_t t2 = 0u;
-    if (n >= a.k && n <= 1024) {
-        if (wave == 0) {
-            uint32_t key[16];
-            const int nj = (n + 63) >> 6;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) key[j] = (j < nj && j * 64 + lane < n) ? s_l[j * 64 + lane] : 0u;
-            uint32_t T = 0u;
-            for (int bit = 31; bit >= 0; --bit) {
-                const uint32_t cand = T | (1u << bit);
-                int c = 0;
-#pragma unroll
-                for (int j = 0; j < 16; ++j)
-                    if (j < nj) c += (int)__popcll(__ballot(j * 64 + lane < n && key[j] >= cand));
-                if (c >= a.k) T = cand;
-            }
-            if (lane == 0) s_prefix = T;
-        }
-        __syncthreads();
-        t2 = s_prefix;
-    } else if (n >= a.k) {
+    if (n >= a.k) {
         for (int shift = 24; shift >= 0; shift -= 8) {
             if (tid < 256) s_hist[tid] = 0;
             __syncthreads();
