@@ -64,6 +64,12 @@ SIGNATURES = {
     "aura_gif_prosody_run": (I, [P, P, P, P, P, F, I, F, F, F, I64, I64, I64, P]),
     "aura_gif_prosody_train_forward": (I, [P, P, P, P, P, P, P, F, I, F, F, F, I64, I64, I64, P]),
     "aura_gif_prosody_backward": (I, [P, P, P, P, P, P, P, P, P, F, I, F, F, F, I64, I64, I64, P]),
+    "aura_lif_run_bf16": (I, [P, P, P, P, P, I64, I64, I64, P]),
+    "aura_lif_train_forward_bf16": (I, [P, P, P, P, P, P, P, I64, I64, P]),
+    "aura_lif_backward_bf16": (I, [P, P, P, P, P, P, P, P, P, I64, I64, P]),
+    "aura_gif_prosody_run_bf16": (I, [P, P, P, P, P, F, I, F, F, F, I64, I64, I64, P]),
+    "aura_gif_prosody_train_forward_bf16": (I, [P, P, P, P, P, P, P, F, I, F, F, F, I64, I64, I64, P]),
+    "aura_gif_prosody_backward_bf16": (I, [P, P, P, P, P, P, P, P, P, F, I, F, F, F, I64, I64, I64, P]),
     "aura_bank_shadow_update": (I, [P, P, P, P, P, I64, I64, I64, P]),
     "aura_knn_search_shadow": (I, [P, P, P, P, P, P, F, I64, I64, I64, I, I32, P, P, P, I64, I, P, P, I, P]),
     "aura_knn_ivf2_workspace_bytes": (I64, [I64, I64, I]),

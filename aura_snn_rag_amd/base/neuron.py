@@ -172,7 +172,7 @@ class AdExNeuron(nn.Module):
 class LifStepFunction(torch.autograd.Function):
     """One differentiable LIF step: (x, mem, beta, threshold, slope) -> (spk, mem_out); backward is
     ``LearnableSurrogateGradient.backward`` of the reference (``neuron.py:80-108``) fused with the
-    membrane recurrence, as ``aura_lif_backward``."""
+    membrane recurrence, as ``aura_lif_backward``.  All five tensors share one dtype, fp32 or bf16."""
 
     @staticmethod
     def forward(ctx, x, mem, beta, threshold, slope):
@@ -191,17 +191,23 @@ class LifStepFunction(torch.autograd.Function):
     def backward(ctx, g_spk, g_mem):
         pre, beta, threshold, slope = ctx.saved_tensors
         size = pre.shape[-1]
-        g_x, g_prev, raw = torch.empty_like(pre), torch.empty_like(pre), torch.empty_like(pre)
-        ops.lif_backward(pre, g_spk.contiguous().view(-1, size), g_mem.contiguous().view(-1, size),
+        g_x, g_prev = torch.empty_like(pre), torch.empty_like(pre)
+        raw = torch.empty(pre.shape, device=pre.device, dtype=torch.float32)
+        ops.lif_backward(pre, g_spk.to(pre.dtype).contiguous().view(-1, size),
+                         g_mem.to(pre.dtype).contiguous().view(-1, size),
                          beta, threshold, slope.contiguous(), g_x, g_prev, raw)
-        return g_x.view(ctx.shape), g_prev.view(ctx.shape), None, None, raw.sum(dim=0)
+        return g_x.view(ctx.shape), g_prev.view(ctx.shape), None, None, raw.sum(dim=0).to(slope.dtype)
 
 
 class VectorizedLIFNeuron(nn.Module):
     """One LIF step per call on ``[..., size]`` input; returns ``(spk, mem)``
     (``neuron.py:115-139``).  ``forward_sequence`` runs a whole ``[B, T, size]`` sequence in one
     launch (what ``EnhancedSpikingNeuron`` does with a Python loop,
-    ``snn_brain_zones.py:73-79``)."""
+    ``snn_brain_zones.py:73-79``).
+
+    dtypes follow the reference's eager ops: a module moved to bf16 fed bf16 input computes in bf16 (each op
+    rounded, ``aura_lif_*_bf16``); any fp32/bf16 mix promotes to fp32 there (``beta * mem + input``), so the
+    bf16 side is widened (exactly) and the fp32 kernels run."""
 
     def __init__(self, size: int, beta: float = 0.5, threshold: float = 0.6,
                  init_slope: float = 15.0, event_bus: Optional[object] = None, name: str = None):
@@ -217,49 +223,69 @@ class VectorizedLIFNeuron(nn.Module):
     def reset_mem(self):
         self.mem = None
 
-    def _prep(self, x: torch.Tensor) -> torch.Tensor:
-        _no_grad_input(x, "VectorizedLIFNeuron")
-        x = _as_f32_input(x, "VectorizedLIFNeuron")
+    def _dtype(self, x: torch.Tensor) -> torch.dtype:
+        who = "VectorizedLIFNeuron"
+        if not x.is_cuda:
+            raise ops.AuraDeviceError(f"{who}: input is on {x.device}; the neuron loops run only as HIP "
+                                      f"kernels (no CPU fallback)")
         if x.shape[-1] != self.size:
             raise ValueError(f"VectorizedLIFNeuron(size={self.size}): last dim is {x.shape[-1]}")
-        return x
+        for t, n in ((x, "input"), (self.beta, "beta"), (self.threshold, "threshold"), (self.slope, "slope")):
+            if t.dtype not in (torch.float32, torch.bfloat16):
+                raise TypeError(f"{who}: {n} is {t.dtype}; fp32 and bf16 are implemented")
+        dt = x.dtype
+        for t in (self.beta, self.threshold) + (() if self.mem is None or self.mem.shape != x.shape else (self.mem,)):
+            dt = torch.promote_types(dt, t.dtype)
+        return dt
+
+    def _consts(self, dt: torch.dtype):
+        return self.beta.to(dt), self.threshold.to(dt)
 
     def _wants_grad(self, x: torch.Tensor) -> bool:
         return torch.is_grad_enabled() and (x.requires_grad or self.slope.requires_grad or
                                             (self.mem is not None and self.mem.requires_grad))
 
     def forward(self, input_: torch.Tensor):
+        dt = self._dtype(input_)
+        beta, thr = self._consts(dt)
         if self._wants_grad(input_):
-            _as_f32_input(input_, "VectorizedLIFNeuron")             # device / dtype checks only
-            x = input_
-            if x.shape[-1] != self.size:
-                raise ValueError(f"VectorizedLIFNeuron(size={self.size}): last dim is {x.shape[-1]}")
+            x = input_.to(dt)
             if self.mem is None or self.mem.shape != x.shape:
                 self.mem = torch.zeros_like(x)
-            spk, self.mem = LifStepFunction.apply(x, self.mem, self.beta, self.threshold, self.slope)
+            # the surrogate's slope keeps its own dtype in the reference (it only enters the backward): widen or
+            # narrow it for the kernel through autograd so that its gradient comes back in the parameter's dtype
+            spk, self.mem = LifStepFunction.apply(x, self.mem.to(dt), beta, thr, self.slope.to(dt))
             return spk, self.mem
-        x = self._prep(input_)
+        x = input_.detach().to(dt).contiguous()
         if self.mem is None or self.mem.shape != x.shape:
             self.mem = torch.zeros_like(x)
-        elif self.mem.requires_grad:
-            self.mem = self.mem.detach().clone()
+        elif self.mem.requires_grad or self.mem.dtype != dt or not self.mem.is_contiguous():
+            self.mem = self.mem.detach().to(dt).contiguous().clone()
         spk = torch.empty_like(x)
         rows = x.numel() // self.size if self.size else 0
         ops.lif_run(x.view(rows, 1, self.size), spk.view(rows, 1, self.size),
-                    self.mem.view(rows, self.size), self.beta, self.threshold)
+                    self.mem.view(rows, self.size), beta, thr)
         return spk, self.mem
 
     def forward_sequence(self, x_seq: torch.Tensor) -> torch.Tensor:
-        x = self._prep(x_seq)
-        if x.dim() != 3:
+        if x_seq.dim() != 3:
             raise ValueError("forward_sequence expects [B, T, size]")
-        B, T, _ = x.shape
-        if self.mem is None or self.mem.shape != (B, self.size):
-            self.mem = torch.zeros(B, self.size, device=x.device, dtype=x.dtype)
-        elif self.mem.requires_grad:
-            self.mem = self.mem.detach().clone()
+        B, T, _ = x_seq.shape
+        if self.mem is not None and self.mem.shape != (B, self.size):
+            self.mem = None
+        saved, self.mem = self.mem, None                   # _dtype() compares mem's shape with a single step's
+        dt = self._dtype(x_seq)
+        if saved is not None:
+            dt = torch.promote_types(dt, saved.dtype)
+        beta, thr = self._consts(dt)
+        x = x_seq.detach().to(dt).contiguous()
+        if saved is None:
+            self.mem = torch.zeros(B, self.size, device=x.device, dtype=dt)
+        else:
+            self.mem = saved.detach().to(dt).contiguous().clone() if (saved.requires_grad or saved.dtype != dt or
+                                                                      not saved.is_contiguous()) else saved
         spikes = torch.empty_like(x)
-        ops.lif_run(x, spikes, self.mem, self.beta, self.threshold)
+        ops.lif_run(x, spikes, self.mem, beta, thr)
         return spikes
 
 

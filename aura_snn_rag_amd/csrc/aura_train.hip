@@ -1,5 +1,5 @@
 // aura_train.hip -- surrogate-gradient training kernels and the prosody-modulated GIF loop
-// (SURVEY.md section 8f-4), fp32 (GIF loop: also bf16), channel-contiguous layout [rows][T][H].
+// (SURVEY.md section 8f-4), fp32 and bf16, channel-contiguous layout [rows][T][H].
 //
 //   GIF   forward (training): the loop of gif_neuron.py:54-69 that also saves, per step, the
 //         pre-clamp potential a_t and the threshold theta_{t-1} it was computed with;
@@ -509,6 +509,215 @@ __global__ __launch_bounds__(256) void gif_prosody_bwd_kernel(GifP p, float stre
     }
 }
 
+// ---- bf16 prosody GIF (ProsodyModulatedGIF under .bfloat16(): x, state AND gains bf16) ----------------------
+// Every op of prosody_gif.py:64-101 rounds its fp32 result to bf16 (Python scalars enter as fp32), so the per
+// (row, t) quantities are themselves rounded chains: scale = clamp(rb(1 - rb(str * rb(g - 1))), .5, 1.5),
+// ae = rb(alpha g).  SAVE = the recording forward (a_t and theta_{t-1} as the bf16 values the graph holds).
+struct ProsodyStep { float g, scale, ae; bool live; };
+__device__ __forceinline__ ProsodyStep prosody_step_bf16(const GifP& p, float strength, const uint16_t* gains, int64_t at) {
+    ProsodyStep r;
+    if (gains == nullptr) { r.g = 1.0f; r.scale = 1.0f; r.ae = p.alpha; r.live = false; return r; }
+    r.g = bf2f(gains[at]);
+    const float raw = rb(1.0f - rb(strength * rb(r.g - 1.0f)));
+    r.scale = fminf(fmaxf(raw, 0.5f), 1.5f);
+    r.live = raw >= 0.5f && raw <= 1.5f;
+    r.ae = rb(p.alpha * r.g);
+    return r;
+}
+// forward intermediates of one step from (a, theta_prev): te, cl, b, n, s (all bf16 values)
+__device__ __forceinline__ void prosody_bf16_mid(const GifP& p, bool mod, float scale, float a, float thp, float& te,
+                                                 float& cl, float& b, float& n, float& s) {
+    te = mod ? rb(thp * scale) : thp;
+    cl = rb(rb(p.Lf * te) * 2.0f);
+    b = fminf(fmaxf(a, -cl), cl);
+    n = rb(b / te);
+    s = fminf(fmaxf(floorf(n), 0.0f), p.Lf);
+}
+
+template <int VEC, bool SAVE>
+__global__ __launch_bounds__(256) void gif_prosody_fwd_bf16_kernel(GifP p, float strength,
+                                                                   const uint16_t* __restrict__ h,
+                                                                   const uint16_t* __restrict__ gains,
+                                                                   uint16_t* __restrict__ spikes, uint16_t* v_io,
+                                                                   uint16_t* th_io, uint16_t* __restrict__ save_a,
+                                                                   uint16_t* __restrict__ save_th, int64_t R,
+                                                                   int64_t T, int64_t C) {
+    const int64_t cv = C / VEC, items = R * cv;
+    const bool mod = gains != nullptr;
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < items;
+         it += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = it / cv, c0 = (it - row * cv) * VEC;
+        float v[VEC], th[VEC];
+        VB<VEC>::ld(v_io + row * C + c0, v);
+        VB<VEC>::ld(th_io + row * C + c0, th);
+        for (int64_t t = 0; t < T; ++t) {
+            const int64_t o = (row * T + t) * C + c0;
+            float x[VEC], a[VEC], s[VEC], thp[VEC];
+            VB<VEC>::ld(h + o, x);
+            const ProsodyStep ps = prosody_step_bf16(p, strength, gains, row * T + t);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                thp[e] = th[e];
+                const float i_t = mod ? rb(x[e] * ps.g) : x[e];
+                a[e] = rb(rb(v[e] * p.decay) + i_t);
+                float te, cl, b, n;
+                prosody_bf16_mid(p, mod, ps.scale, a[e], th[e], te, cl, b, n, s[e]);
+                v[e] = rb(b - rb(s[e] * te));
+                if (p.alpha > 0.0f)
+                    th[e] = rb(rb(th[e] + rb(ps.ae * s[e])) - rb(ps.ae * rb(th[e] - p.thr0)));
+            }
+            VB<VEC>::st(spikes + o, s);
+            if (SAVE) { VB<VEC>::st(save_a + o, a); VB<VEC>::st(save_th + o, thp); }
+        }
+        VB<VEC>::st(v_io + row * C + c0, v);
+        VB<VEC>::st(th_io + row * C + c0, th);
+    }
+}
+
+// BPTT of that loop: the fp32 chain of gif_prosody_bwd_kernel evaluated on the forward's bf16-rounded
+// intermediates; state gradients stay in fp32 registers over the T steps, g_h is rounded once on the way out,
+// g_gains is accumulated in fp32 (the caller rounds it).
+template <int VEC>
+__global__ __launch_bounds__(256) void gif_prosody_bwd_bf16_kernel(GifP p, float strength,
+                                                                   const uint16_t* __restrict__ save_a,
+                                                                   const uint16_t* __restrict__ save_th,
+                                                                   const uint16_t* __restrict__ h,
+                                                                   const uint16_t* __restrict__ gains,
+                                                                   const uint16_t* __restrict__ g_spikes,
+                                                                   uint16_t* __restrict__ g_h, float* __restrict__ g_gains,
+                                                                   uint16_t* gv_io, uint16_t* gth_io, int64_t R, int64_t T,
+                                                                   int64_t C) {
+    const int64_t cv = C / VEC, items = R * cv;
+    const bool mod = gains != nullptr;
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < items;
+         it += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = it / cv, c0 = (it - row * cv) * VEC;
+        float gv[VEC], gth[VEC];
+        VB<VEC>::ld(gv_io + row * C + c0, gv);
+        VB<VEC>::ld(gth_io + row * C + c0, gth);
+        for (int64_t t = T - 1; t >= 0; --t) {
+            const int64_t o = (row * T + t) * C + c0;
+            float a[VEC], thp[VEC], gs[VEC], gh[VEC], x[VEC];
+            VB<VEC>::ld(save_a + o, a);
+            VB<VEC>::ld(save_th + o, thp);
+            VB<VEC>::ld(g_spikes + o, gs);
+            VB<VEC>::ld(h + o, x);
+            const ProsodyStep ps = prosody_step_bf16(p, strength, gains, row * T + t);
+            float gg = 0.0f;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                float te, cl, b, n, s;
+                prosody_bf16_mid(p, mod, ps.scale, a[e], thp[e], te, cl, b, n, s);
+                float gth_prev = gth[e];
+                float gs_tot = gs[e];
+                if (p.alpha > 0.0f) {
+                    gs_tot = gs_tot + ps.ae * gth[e];
+                    gth_prev = gth_prev - ps.ae * gth[e];
+                    if (mod) gg += gth[e] * (s - (thp[e] - p.thr0)) * p.alpha;
+                }
+                gs_tot = gs_tot - te * gv[e];
+                float gte = -s * gv[e];
+                float gb = gv[e];
+                const float dist = fabsf(n - rintf(n));
+                const float tri = fminf(fmaxf(1.0f - 2.0f * dist, 0.0f), 1.0f);
+                const float sur = (n >= 0.0f && n <= p.Lf + 1.0f) ? tri : 0.0f;
+                const float gn = gs_tot * sur;
+                gb = gb + gn / te;
+                gte = gte + (-gn * b / (te * te));
+                float ga = 0.0f, gcl = 0.0f;
+                if (a[e] < -cl) gcl = -gb;
+                else if (a[e] > cl) gcl = gb;
+                else ga = gb;
+                gte = gte + gcl * (2.0f * p.Lf);
+                gth_prev = gth_prev + (mod ? gte * ps.scale : gte);
+                if (ps.live) gg += gte * thp[e] * (-strength);
+                gh[e] = mod ? ga * ps.g : ga;
+                if (mod) gg += ga * x[e];
+                gv[e] = ga * p.decay;
+                gth[e] = gth_prev;
+            }
+            VB<VEC>::st(g_h + o, gh);
+            if (mod && g_gains) atomicAdd(g_gains + row * T + t, gg);
+        }
+        VB<VEC>::st(gv_io + row * C + c0, gv);
+        VB<VEC>::st(gth_io + row * C + c0, gth);
+    }
+}
+
+// ---- bf16 LIF (VectorizedLIFNeuron under .bfloat16(): beta, threshold, slope and the input bf16) ------------
+// neuron.py:135-139 with each op rounded: mm = rb(rb(beta m) + x); pre = rb(mm - thr); s = pre > 0;
+// m' = rb(mm - s thr).  TRAIN: one step that also saves pre (mem_in is left alone); else the T-step loop.
+template <int VEC, bool TRAIN>
+__global__ __launch_bounds__(256) void lif_bf16_kernel(const uint16_t* __restrict__ x, const uint16_t* mem_in,
+                                                       const uint16_t* __restrict__ beta,
+                                                       const uint16_t* __restrict__ thr, uint16_t* __restrict__ spk,
+                                                       uint16_t* mem_out, uint16_t* __restrict__ pre, int64_t B,
+                                                       int64_t T, int64_t C) {
+    const int64_t cv = C / VEC, items = B * cv;
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < items;
+         it += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = it / cv, c0 = (it - row * cv) * VEC;
+        float m[VEC], bt[VEC], th[VEC];
+        VB<VEC>::ld(mem_in + row * C + c0, m);
+        VB<VEC>::ld(beta + c0, bt);
+        VB<VEC>::ld(thr + c0, th);
+        for (int64_t t = 0; t < T; ++t) {
+            const int64_t o = (row * T + t) * C + c0;
+            float xv[VEC], s[VEC], pr[VEC];
+            VB<VEC>::ld(x + o, xv);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const float mm = rb(rb(bt[e] * m[e]) + xv[e]);
+                pr[e] = rb(mm - th[e]);
+                s[e] = pr[e] > 0.0f ? 1.0f : 0.0f;
+                m[e] = rb(mm - s[e] * th[e]);
+            }
+            VB<VEC>::st(spk + o, s);
+            if (TRAIN) VB<VEC>::st(pre + o, pr);
+        }
+        VB<VEC>::st(mem_out + row * C + c0, m);
+    }
+}
+
+// the fp32 formulas of lif_bwd_kernel on the saved bf16 pre; g_x, g_mem_prev rounded once, raw_slope fp32
+template <int VEC>
+__global__ __launch_bounds__(256) void lif_bwd_bf16_kernel(const uint16_t* __restrict__ pre,
+                                                           const uint16_t* __restrict__ g_spk,
+                                                           const uint16_t* __restrict__ g_mem,
+                                                           const uint16_t* __restrict__ beta,
+                                                           const uint16_t* __restrict__ thr,
+                                                           const uint16_t* __restrict__ slope,
+                                                           uint16_t* __restrict__ g_x, uint16_t* __restrict__ g_mem_prev,
+                                                           float* __restrict__ raw_slope, int64_t B, int64_t C) {
+    const int64_t cv = C / VEC, items = B * cv;
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < items;
+         it += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = it / cv, c0 = (it - row * cv) * VEC;
+        float pr[VEC], gs[VEC], gm[VEC], bt[VEC], th[VEC], sl[VEC], gx[VEC], gp[VEC];
+        VB<VEC>::ld(pre + row * C + c0, pr);
+        VB<VEC>::ld(g_spk + row * C + c0, gs);
+        VB<VEC>::ld(g_mem + row * C + c0, gm);
+        VB<VEC>::ld(beta + c0, bt);
+        VB<VEC>::ld(thr + c0, th);
+        VB<VEC>::ld(slope + c0, sl);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const float g_s = gs[e] - gm[e] * th[e];
+            const float den = fabsf(sl[e] * pr[e]) + 1.0f;
+            const float g_pre = g_s * (sl[e] / (den * den));
+            const float g_m = gm[e] + g_pre;
+            gx[e] = g_m;
+            gp[e] = bt[e] * g_m;
+            const float ap = fabsf(pr[e]);
+            const float sg = pr[e] > 0.0f ? 1.0f : (pr[e] < 0.0f ? -1.0f : 0.0f);
+            const float den2 = sl[e] * ap + 1.0f;
+            raw_slope[row * C + c0 + e] = -g_s * ap * sg / (den2 * den2);
+        }
+        VB<VEC>::st(g_x + row * C + c0, gx);
+        VB<VEC>::st(g_mem_prev + row * C + c0, gp);
+    }
+}
+
 }  // namespace
 
 #define AURA_VEC_DISPATCH(KERNEL, ITEMS4, ITEMS1, VECOK, ...)                                       \
@@ -656,6 +865,105 @@ int aura_gif_prosody_backward(const float* save_a, const float* save_theta, cons
     const GifP p{decay, (float)L, alpha, threshold};
     AURA_VEC_DISPATCH(gif_prosody_bwd_kernel, rows * (H / 4), rows * H, vec, p, strength, save_a, save_theta, h,
                       gains, g_spikes, g_h, g_gains, g_v, g_theta, rows, T, H);
+    return check_launch();
+}
+
+#define AURA_VEC8_DISPATCH(KERNEL8, KERNEL1, ROWS, H, VECOK, ...)                                        \
+    do {                                                                                                \
+        if (VECOK) hipLaunchKernelGGL(KERNEL8, dim3(grid_for((ROWS) * ((H) / 8))), dim3(256), 0, s, __VA_ARGS__); \
+        else hipLaunchKernelGGL(KERNEL1, dim3(grid_for((ROWS) * (H))), dim3(256), 0, s, __VA_ARGS__);    \
+    } while (0)
+
+int aura_gif_prosody_run_bf16(const uint16_t* h, const uint16_t* gains, uint16_t* spikes, uint16_t* v, uint16_t* theta,
+                              float decay, int L, float alpha, float threshold, float strength, int64_t rows,
+                              int64_t T, int64_t H, void* stream) {
+    if (rows < 0 || T < 0 || H < 0 || L < 0 || L > 256) return AURA_E_INVAL;
+    if (rows == 0 || H == 0) return AURA_OK;
+    if (!v || !theta || (T && (!h || !spikes))) return AURA_E_INVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool vec = H % 8 == 0 && aligned16(h) && aligned16(spikes) && aligned16(v) && aligned16(theta);
+    const GifP p{decay, (float)L, alpha, threshold};
+    uint16_t* none = nullptr;
+    AURA_VEC8_DISPATCH((gif_prosody_fwd_bf16_kernel<8, false>), (gif_prosody_fwd_bf16_kernel<1, false>), rows, H, vec, p,
+                       strength, h, gains, spikes, v, theta, none, none, rows, T, H);
+    return check_launch();
+}
+
+int aura_gif_prosody_train_forward_bf16(const uint16_t* h, const uint16_t* gains, uint16_t* spikes, uint16_t* v,
+                                        uint16_t* theta, uint16_t* save_a, uint16_t* save_theta, float decay, int L,
+                                        float alpha, float threshold, float strength, int64_t rows, int64_t T,
+                                        int64_t H, void* stream) {
+    if (rows < 0 || T < 0 || H < 0 || L < 0 || L > 256) return AURA_E_INVAL;
+    if (rows == 0 || H == 0) return AURA_OK;
+    if (!v || !theta || (T && (!h || !spikes || !save_a || !save_theta))) return AURA_E_INVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool vec = H % 8 == 0 && aligned16(h) && aligned16(spikes) && aligned16(v) && aligned16(theta) &&
+                     aligned16(save_a) && aligned16(save_theta);
+    const GifP p{decay, (float)L, alpha, threshold};
+    AURA_VEC8_DISPATCH((gif_prosody_fwd_bf16_kernel<8, true>), (gif_prosody_fwd_bf16_kernel<1, true>), rows, H, vec, p,
+                       strength, h, gains, spikes, v, theta, save_a, save_theta, rows, T, H);
+    return check_launch();
+}
+
+int aura_gif_prosody_backward_bf16(const uint16_t* save_a, const uint16_t* save_theta, const uint16_t* h,
+                                   const uint16_t* gains, const uint16_t* g_spikes, uint16_t* g_h, float* g_gains,
+                                   uint16_t* g_v, uint16_t* g_theta, float decay, int L, float alpha, float threshold,
+                                   float strength, int64_t rows, int64_t T, int64_t H, void* stream) {
+    if (rows < 0 || T < 0 || H < 0 || L < 0 || L > 256) return AURA_E_INVAL;
+    if (rows == 0 || H == 0) return AURA_OK;
+    if (!g_v || !g_theta || (T && (!save_a || !save_theta || !h || !g_spikes || !g_h))) return AURA_E_INVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool vec = H % 8 == 0 && aligned16(save_a) && aligned16(save_theta) && aligned16(h) &&
+                     aligned16(g_spikes) && aligned16(g_h) && aligned16(g_v) && aligned16(g_theta);
+    const GifP p{decay, (float)L, alpha, threshold};
+    AURA_VEC8_DISPATCH((gif_prosody_bwd_bf16_kernel<8>), (gif_prosody_bwd_bf16_kernel<1>), rows, H, vec, p, strength,
+                       save_a, save_theta, h, gains, g_spikes, g_h, g_gains, g_v, g_theta, rows, T, H);
+    return check_launch();
+}
+
+int aura_lif_run_bf16(const uint16_t* x, uint16_t* spikes, uint16_t* mem, const uint16_t* beta,
+                      const uint16_t* threshold, int64_t B, int64_t T, int64_t size, void* stream) {
+    if (B < 0 || T < 0 || size < 0) return AURA_E_INVAL;
+    if (B == 0 || size == 0 || T == 0) return AURA_OK;
+    if (!x || !spikes || !mem || !beta || !threshold) return AURA_E_INVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool vec = size % 8 == 0 && aligned16(x) && aligned16(spikes) && aligned16(mem) && aligned16(beta) &&
+                     aligned16(threshold);
+    uint16_t* none = nullptr;
+    const uint16_t* mem_in = mem;
+    AURA_VEC8_DISPATCH((lif_bf16_kernel<8, false>), (lif_bf16_kernel<1, false>), B, size, vec, x, mem_in, beta, threshold,
+                       spikes, mem, none, B, T, size);
+    return check_launch();
+}
+
+int aura_lif_train_forward_bf16(const uint16_t* x, const uint16_t* mem_in, const uint16_t* beta,
+                                const uint16_t* threshold, uint16_t* spikes, uint16_t* mem_out, uint16_t* pre,
+                                int64_t B, int64_t size, void* stream) {
+    if (B < 0 || size < 0) return AURA_E_INVAL;
+    if (B == 0 || size == 0) return AURA_OK;
+    if (!x || !mem_in || !beta || !threshold || !spikes || !mem_out || !pre) return AURA_E_INVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool vec = size % 8 == 0 && aligned16(x) && aligned16(mem_in) && aligned16(beta) &&
+                     aligned16(threshold) && aligned16(spikes) && aligned16(mem_out) && aligned16(pre);
+    const int64_t one = 1;
+    AURA_VEC8_DISPATCH((lif_bf16_kernel<8, true>), (lif_bf16_kernel<1, true>), B, size, vec, x, mem_in, beta, threshold,
+                       spikes, mem_out, pre, B, one, size);
+    return check_launch();
+}
+
+int aura_lif_backward_bf16(const uint16_t* pre, const uint16_t* g_spikes, const uint16_t* g_mem, const uint16_t* beta,
+                           const uint16_t* threshold, const uint16_t* slope, uint16_t* g_x, uint16_t* g_mem_prev,
+                           float* raw_slope, int64_t B, int64_t size, void* stream) {
+    if (B < 0 || size < 0) return AURA_E_INVAL;
+    if (B == 0 || size == 0) return AURA_OK;
+    if (!pre || !g_spikes || !g_mem || !beta || !threshold || !slope || !g_x || !g_mem_prev || !raw_slope)
+        return AURA_E_INVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool vec = size % 8 == 0 && aligned16(pre) && aligned16(g_spikes) && aligned16(g_mem) &&
+                     aligned16(beta) && aligned16(threshold) && aligned16(slope) && aligned16(g_x) &&
+                     aligned16(g_mem_prev);
+    AURA_VEC8_DISPATCH((lif_bwd_bf16_kernel<8>), (lif_bwd_bf16_kernel<1>), B, size, vec, pre, g_spikes, g_mem, beta,
+                       threshold, slope, g_x, g_mem_prev, raw_slope, B, size);
     return check_launch();
 }
 

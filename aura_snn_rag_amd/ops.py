@@ -100,15 +100,19 @@ def adex_run_btd(I, spikes, V, w, params: Sequence[float]) -> None:
 
 
 def lif_run(x, spikes, mem, beta, threshold) -> None:
-    """x, spikes: [B, T, size]; mem: [B, size] in/out; beta, threshold: [size]."""
+    """x, spikes: [B, T, size]; mem: [B, size] in/out; beta, threshold: [size].  fp32, or all five bf16 (a
+    module moved to bf16: every op rounds to bf16)."""
+    dt = x.dtype
+    if dt not in (torch.float32, torch.bfloat16):
+        raise TypeError(f"lif_run supports fp32 and bf16, got {dt}")
     for t, n in ((x, "x"), (spikes, "spikes"), (mem, "mem"), (beta, "beta"), (threshold, "threshold")):
-        _need(t, n, torch.float32)
+        _need(t, n, dt)
     B, T, size = x.shape
     if spikes.shape != x.shape or mem.shape != (B, size) or beta.numel() != size or \
             threshold.numel() != size:
         raise ValueError("lif_run: shape mismatch")
-    check(lib().aura_lif_run(_p(x), _p(spikes), _p(mem), _p(beta), _p(threshold), B, T, size,
-                             _stream()), "aura_lif_run")
+    fn = lib().aura_lif_run if dt == torch.float32 else lib().aura_lif_run_bf16
+    check(fn(_p(x), _p(spikes), _p(mem), _p(beta), _p(threshold), B, T, size, _stream()), "aura_lif_run")
 
 
 def gif_run(h, out, v, theta, decay: float, L: int, alpha: float, threshold: float, T: int,
@@ -134,7 +138,7 @@ def gif_run(h, out, v, theta, decay: float, L: int, alpha: float, threshold: flo
 
 
 # ---------------------------------------------------------------------------------------
-# surrogate-gradient training path + prosody-modulated GIF (fp32)
+# surrogate-gradient training path + prosody-modulated GIF (fp32 and bf16)
 # ---------------------------------------------------------------------------------------
 
 def _same_f32(shape, *named) -> None:
@@ -190,58 +194,81 @@ def gif_backward(save_a, save_theta, g_spikes, g_h, g_v, g_theta, decay: float, 
 
 
 def lif_train_forward(x, mem_in, beta, threshold, spikes, mem_out, pre) -> None:
+    """One recording LIF step, [B, size]; fp32 or all bf16."""
     B, size = x.shape
-    _same_f32((B, size), (x, "x"), (mem_in, "mem_in"), (spikes, "spikes"), (mem_out, "mem_out"), (pre, "pre"))
-    _same_f32((size,), (beta, "beta"), (threshold, "threshold"))
-    check(lib().aura_lif_train_forward(_p(x), _p(mem_in), _p(beta), _p(threshold), _p(spikes), _p(mem_out),
-                                       _p(pre), B, size, _stream()), "aura_lif_train_forward")
+    dt = x.dtype
+    if dt not in (torch.float32, torch.bfloat16):
+        raise TypeError(f"lif_train_forward supports fp32 and bf16, got {dt}")
+    _same_dtype(dt, (B, size), (x, "x"), (mem_in, "mem_in"), (spikes, "spikes"), (mem_out, "mem_out"), (pre, "pre"))
+    _same_dtype(dt, (size,), (beta, "beta"), (threshold, "threshold"))
+    fn = lib().aura_lif_train_forward if dt == torch.float32 else lib().aura_lif_train_forward_bf16
+    check(fn(_p(x), _p(mem_in), _p(beta), _p(threshold), _p(spikes), _p(mem_out), _p(pre), B, size, _stream()),
+          "aura_lif_train_forward")
 
 
 def lif_backward(pre, g_spikes, g_mem, beta, threshold, slope, g_x, g_mem_prev, raw_slope) -> None:
+    """raw_slope [B, size] is fp32 in both forms (sum it over the batch for d/d slope)."""
     B, size = pre.shape
-    _same_f32((B, size), (pre, "pre"), (g_spikes, "g_spikes"), (g_mem, "g_mem"), (g_x, "g_x"),
-              (g_mem_prev, "g_mem_prev"), (raw_slope, "raw_slope"))
-    _same_f32((size,), (beta, "beta"), (threshold, "threshold"), (slope, "slope"))
-    check(lib().aura_lif_backward(_p(pre), _p(g_spikes), _p(g_mem), _p(beta), _p(threshold), _p(slope),
-                                  _p(g_x), _p(g_mem_prev), _p(raw_slope), B, size, _stream()),
-          "aura_lif_backward")
+    dt = pre.dtype
+    if dt not in (torch.float32, torch.bfloat16):
+        raise TypeError(f"lif_backward supports fp32 and bf16, got {dt}")
+    _same_dtype(dt, (B, size), (pre, "pre"), (g_spikes, "g_spikes"), (g_mem, "g_mem"), (g_x, "g_x"),
+                (g_mem_prev, "g_mem_prev"))
+    _same_f32((B, size), (raw_slope, "raw_slope"))
+    _same_dtype(dt, (size,), (beta, "beta"), (threshold, "threshold"), (slope, "slope"))
+    fn = lib().aura_lif_backward if dt == torch.float32 else lib().aura_lif_backward_bf16
+    check(fn(_p(pre), _p(g_spikes), _p(g_mem), _p(beta), _p(threshold), _p(slope), _p(g_x), _p(g_mem_prev),
+             _p(raw_slope), B, size, _stream()), "aura_lif_backward")
+
+
+def _prosody_dtype(h, who: str):
+    if h.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError(f"{who} supports fp32 and bf16, got {h.dtype}")
+    return h.dtype
 
 
 def gif_prosody_run(h, gains, spikes, v, theta, decay: float, L: int, alpha: float, threshold: float,
                     strength: float) -> None:
-    """h, spikes [rows, T, H]; gains [rows, T] or None; v, theta [rows, H] in/out."""
+    """h, spikes [rows, T, H]; gains [rows, T] or None; v, theta [rows, H] in/out.  fp32, or everything
+    (gains included) bf16."""
     rows, T, H = h.shape
-    _same_f32((rows, T, H), (h, "h"), (spikes, "spikes"))
-    _same_f32((rows, H), (v, "v"), (theta, "theta"))
+    dt = _prosody_dtype(h, "gif_prosody_run")
+    _same_dtype(dt, (rows, T, H), (h, "h"), (spikes, "spikes"))
+    _same_dtype(dt, (rows, H), (v, "v"), (theta, "theta"))
     if gains is not None:
-        _same_f32((rows, T), (gains, "gains"))
-    check(lib().aura_gif_prosody_run(_p(h), _p(gains), _p(spikes), _p(v), _p(theta), decay, int(L), alpha,
-                                     threshold, strength, rows, T, H, _stream()), "aura_gif_prosody_run")
+        _same_dtype(dt, (rows, T), (gains, "gains"))
+    fn = lib().aura_gif_prosody_run if dt == torch.float32 else lib().aura_gif_prosody_run_bf16
+    check(fn(_p(h), _p(gains), _p(spikes), _p(v), _p(theta), decay, int(L), alpha, threshold, strength, rows, T, H,
+             _stream()), "aura_gif_prosody_run")
 
 
 def gif_prosody_train_forward(h, gains, spikes, v, theta, save_a, save_theta, decay: float, L: int, alpha: float,
                               threshold: float, strength: float) -> None:
     rows, T, H = h.shape
-    _same_f32((rows, T, H), (h, "h"), (spikes, "spikes"), (save_a, "save_a"), (save_theta, "save_theta"))
-    _same_f32((rows, H), (v, "v"), (theta, "theta"))
+    dt = _prosody_dtype(h, "gif_prosody_train_forward")
+    _same_dtype(dt, (rows, T, H), (h, "h"), (spikes, "spikes"), (save_a, "save_a"), (save_theta, "save_theta"))
+    _same_dtype(dt, (rows, H), (v, "v"), (theta, "theta"))
     if gains is not None:
-        _same_f32((rows, T), (gains, "gains"))
-    check(lib().aura_gif_prosody_train_forward(_p(h), _p(gains), _p(spikes), _p(v), _p(theta), _p(save_a),
-                                               _p(save_theta), decay, int(L), alpha, threshold, strength, rows, T, H,
-                                               _stream()), "aura_gif_prosody_train_forward")
+        _same_dtype(dt, (rows, T), (gains, "gains"))
+    fn = lib().aura_gif_prosody_train_forward if dt == torch.float32 else lib().aura_gif_prosody_train_forward_bf16
+    check(fn(_p(h), _p(gains), _p(spikes), _p(v), _p(theta), _p(save_a), _p(save_theta), decay, int(L), alpha,
+             threshold, strength, rows, T, H, _stream()), "aura_gif_prosody_train_forward")
 
 
 def gif_prosody_backward(save_a, save_theta, h, gains, g_spikes, g_h, g_gains, g_v, g_theta, decay: float, L: int,
                          alpha: float, threshold: float, strength: float) -> None:
-    """g_gains [rows, T] must be zero on entry (channels are accumulated into it)."""
+    """g_gains [rows, T], fp32 in both forms, must be zero on entry (channels are accumulated into it)."""
     rows, T, H = save_a.shape
-    _same_f32((rows, T, H), (save_a, "save_a"), (save_theta, "save_theta"), (h, "h"), (g_spikes, "g_spikes"), (g_h, "g_h"))
-    _same_f32((rows, H), (g_v, "g_v"), (g_theta, "g_theta"))
+    dt = _prosody_dtype(save_a, "gif_prosody_backward")
+    _same_dtype(dt, (rows, T, H), (save_a, "save_a"), (save_theta, "save_theta"), (h, "h"), (g_spikes, "g_spikes"),
+                (g_h, "g_h"))
+    _same_dtype(dt, (rows, H), (g_v, "g_v"), (g_theta, "g_theta"))
     if gains is not None:
-        _same_f32((rows, T), (gains, "gains"), (g_gains, "g_gains"))
-    check(lib().aura_gif_prosody_backward(_p(save_a), _p(save_theta), _p(h), _p(gains), _p(g_spikes), _p(g_h),
-                                          _p(g_gains), _p(g_v), _p(g_theta), decay, int(L), alpha, threshold, strength,
-                                          rows, T, H, _stream()), "aura_gif_prosody_backward")
+        _same_dtype(dt, (rows, T), (gains, "gains"))
+        _same_f32((rows, T), (g_gains, "g_gains"))
+    fn = lib().aura_gif_prosody_backward if dt == torch.float32 else lib().aura_gif_prosody_backward_bf16
+    check(fn(_p(save_a), _p(save_theta), _p(h), _p(gains), _p(g_spikes), _p(g_h), _p(g_gains), _p(g_v), _p(g_theta),
+             decay, int(L), alpha, threshold, strength, rows, T, H, _stream()), "aura_gif_prosody_backward")
 
 
 # ---------------------------------------------------------------------------------------

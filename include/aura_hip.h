@@ -421,6 +421,34 @@ int aura_gif_prosody_backward(const float* save_a, const float* save_theta, cons
                               float decay, int L, float alpha, float threshold, float strength, int64_t rows,
                               int64_t T, int64_t H, void* stream);
 
+/* bf16 forms of the LIF step and of the prosody GIF (bit patterns, uint16_t) for modules moved to bf16 with
+ * .bfloat16() / .to(torch.bfloat16): buffers, parameters, input, state AND gains are bf16 and every op of
+ * src/base/neuron.py:135-139 / src/core/language_zone/prosody_gif.py:64-101 rounds its fp32 result to bf16
+ * (Python scalars enter as fp32), which the forward kernels reproduce bit for bit.  The backward kernels
+ * evaluate the fp32 chains of aura_lif_backward / aura_gif_prosody_backward on the saved bf16 values with the
+ * forward's roundings re-applied, carry state gradients in fp32 and round once on the way out; raw_slope and
+ * g_gains stay fp32 (the caller reduces / rounds them).  L <= 256.  (A bf16 input to an fp32 module, or fp32
+ * gains with a bf16 input, promote to fp32 in the reference: the host runs those on the fp32 entry points.) */
+int aura_lif_run_bf16(const uint16_t* x, uint16_t* spikes, uint16_t* mem, const uint16_t* beta,
+                      const uint16_t* threshold, int64_t B, int64_t T, int64_t size, void* stream);
+int aura_lif_train_forward_bf16(const uint16_t* x, const uint16_t* mem_in, const uint16_t* beta,
+                                const uint16_t* threshold, uint16_t* spikes, uint16_t* mem_out, uint16_t* pre,
+                                int64_t B, int64_t size, void* stream);
+int aura_lif_backward_bf16(const uint16_t* pre, const uint16_t* g_spikes, const uint16_t* g_mem, const uint16_t* beta,
+                           const uint16_t* threshold, const uint16_t* slope, uint16_t* g_x, uint16_t* g_mem_prev,
+                           float* raw_slope, int64_t B, int64_t size, void* stream);
+int aura_gif_prosody_run_bf16(const uint16_t* h, const uint16_t* gains, uint16_t* spikes, uint16_t* v, uint16_t* theta,
+                              float decay, int L, float alpha, float threshold, float strength, int64_t rows,
+                              int64_t T, int64_t H, void* stream);
+int aura_gif_prosody_train_forward_bf16(const uint16_t* h, const uint16_t* gains, uint16_t* spikes, uint16_t* v,
+                                        uint16_t* theta, uint16_t* save_a, uint16_t* save_theta, float decay, int L,
+                                        float alpha, float threshold, float strength, int64_t rows, int64_t T,
+                                        int64_t H, void* stream);
+int aura_gif_prosody_backward_bf16(const uint16_t* save_a, const uint16_t* save_theta, const uint16_t* h,
+                                   const uint16_t* gains, const uint16_t* g_spikes, uint16_t* g_h, float* g_gains,
+                                   uint16_t* g_v, uint16_t* g_theta, float decay, int L, float alpha, float threshold,
+                                   float strength, int64_t rows, int64_t T, int64_t H, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Brain-zone projection
  * ------------------------------------------------------------------------------------- */

@@ -105,7 +105,8 @@ def lif_step(x: torch.Tensor, mem: torch.Tensor, beta: torch.Tensor, threshold: 
     """One vectorised LIF step.  Restates ``src/base/neuron.py:135-139`` (forward value of the
     surrogate, ``neuron.py:75-77``, is ``(input > 0)``)."""
     mem = beta * mem + x
-    spk = ((mem - threshold) > 0).to(x.dtype)
+    pre = mem - threshold
+    spk = (pre > 0).to(pre.dtype)                     # the surrogate casts to ITS input's dtype (neuron.py:77)
     mem = mem - spk * threshold
     return spk, mem
 
