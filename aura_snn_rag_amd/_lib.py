@@ -88,6 +88,7 @@ SIGNATURES = {
     "aura_knn_search_ivf2_signal": (I, [P, P, P, P, P, P, P, P, P, P, I64, I64, P, F, I64, I64, I, P, I, P, I32, P, P, P,
                                         I64, P, P, U32, P]),
     "aura_profile_begin": (I, [I]),
+    "aura_debug_cs_flags": (I, [I]),
     "aura_profile_end": (I, [P, I]),
     "aura_profile_last_scan": (I, [P, P]),
     "aura_profile_last_scan_kind": (I, []),

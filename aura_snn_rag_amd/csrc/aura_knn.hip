@@ -2171,6 +2171,14 @@ struct ProfileState {
     int64_t rows = 0, nq = 0;   // rows x queries scored by the last profiled main-scan launch
     int kind = 0;               // 0 = fp32 MFMA scan, 1 = bf16 prefilter scan
 };
+// AURA_CS_DBG: ablation / timing switches of the scan kernels (results are invalid when non-zero); read from the
+// environment once, replaceable through aura_debug_cs_flags (A/B runs inside one process: same allocations, same
+// clocks -- successive processes on one box differ by +-5 %, more than most of the effects looked for)
+int g_cs_dbg = -1;
+inline int cs_dbg_flags() {
+    if (g_cs_dbg < 0) g_cs_dbg = getenv("AURA_CS_DBG") ? (atoi(getenv("AURA_CS_DBG")) & 0x7fffffff) : 0;
+    return g_cs_dbg;
+}
 ProfileState g_prof;            // one measurement session per PROCESS (bench.py / tests; aura_profile_begin documents it):
                                 // events belong to the device that was current at aura_profile_begin
 
@@ -2308,12 +2316,13 @@ inline int launch_refine_for(const RefineArgs& r_in, int nqb, int64_t D, int cus
     return launch_refine(std::integral_constant<int, 16>{}, std::integral_constant<int, 256>{});
 }
 
-// AURA_CS_DBG bit 64: per-wave phase times of a filter launch (written by the kernel into `buf`)
+// AURA_CS_DBG bit 64 (builds with -DAURA_CS_TIMERS=1 only): per-wave phase times of a filter launch (written by
+// the kernel into `buf`)
 inline void print_cs_phases(hipStream_t s, const float* buf, int cus) {
     (void)hipStreamSynchronize(s);
     std::vector<float> h((size_t)cus * 64);
     (void)hipMemcpy(h.data(), buf, h.size() * 4, hipMemcpyDeviceToHost);
-    static const char* const names[6] = {"wait+barrier", "check+issue", "-", "mfma loop", "write-out", "epilogue"};
+    static const char* const names[6] = {"DMA wait", "check+issue", "segment set-up", "mfma loop", "barrier", "write-out+epilogue"};
     for (int role = 0; role < 2; ++role) {
         double sum[6] = {0, 0, 0, 0, 0, 0}, tiles = 0; int waves = 0;
         for (int g = 0; g < cus; ++g)
@@ -2331,6 +2340,15 @@ inline void print_cs_phases(hipStream_t s, const float* buf, int cus) {
             tot += sum[i];
         }
         fprintf(stderr, " total %.2f us\n", tot / waves * 0.01);
+    }
+    // per-wave busy / barrier times of a few workgroups: is the barrier skew systematic (one wave always last)?
+    for (int g = 0; g < cus && g < 4; ++g) {
+        fprintf(stderr, "[cs phases] wg %d [dma issue setup mma barrier epi] us per wave:", g);
+        for (int wv = 0; wv < 8; ++wv) {
+            const float* o = &h[((size_t)g * 8 + wv) * 8];
+            fprintf(stderr, " [%.0f %.0f %.0f %.0f %.0f %.0f]", o[0] * 0.01, o[1] * 0.01, o[2] * 0.01, o[3] * 0.01, o[4] * 0.01, o[5] * 0.01);
+        }
+        fprintf(stderr, "\n");
     }
     // whole-kernel time per workgroup (wave 0), tile-loop time, tiles: spread over the workgroups
     double kmin = 1e30, kmax = 0, ksum = 0, lmin = 1e30, lmax = 0, lsum = 0; int n = 0;
@@ -2406,7 +2424,7 @@ inline int run_coarse_pass(const float* bank, const uint16_t* bank16, const floa
     CoarseArgs c{};
     c.bank = bank; c.rowc = w.rowc; c.qhat = w.qhat; c.inv_q = w.inv_q; c.eq = w.eq;
     c.bank16 = use16 ? bank16 : nullptr;
-    static const int cs_dbg = getenv("AURA_CS_DBG") ? atoi(getenv("AURA_CS_DBG")) : 0;
+    const int cs_dbg = cs_dbg_flags();
     c.dbg = cs_dbg;
     c.N = N; c.D = D; c.nq = nqb;
     c.thr = w.thr; c.cnt = w.cnt; c.cand_scores = w.cand_scores; c.cand_idx = w.cand_idx;
@@ -2435,7 +2453,7 @@ inline int run_coarse_pass(const float* bank, const uint16_t* bank16, const floa
 
     c.n_tiles = (N + CS_ROWS - 1) / CS_ROWS; c.gmax = nullptr; c.gshift = 0;
     static int tm_left = 3;                                  // AURA_CS_DBG bit 64: phase times of the first launches
-    const bool tm = (cs_dbg & 64) && tm_left > 0;
+    const bool tm = CS_TIMERS && (cs_dbg & 64) && tm_left > 0;
     if (tm) {
         c.gmax = w.gmax;
         (void)hipMemsetAsync(w.gmax, 0, (size_t)cus * 8 * 8 * 4, s);
@@ -2462,7 +2480,7 @@ inline int run_coarse_pass(const float* bank, const uint16_t* bank16, const floa
     r.cand_scores = w.cand_scores; r.cand_idx = w.cand_idx; r.cap = w.cap; r.idx_base = idx_base;
     r.out_scores = out_scores; r.out_idx = out_idx; r.overflow = overflow_out;
     static int rtm_left = 3;                                 // AURA_CS_DBG bit 128: refine phase times
-    const bool rtm = (cs_dbg & 128) && rtm_left > 0;
+    const bool rtm = CS_TIMERS && (cs_dbg & 128) && rtm_left > 0;
     if (rtm) r.dbg_out = w.gmax;
     if ((rc = launch_refine_for(r, nqb, D, cus, s, w.heavy))) return rc;
     if (rtm) {
@@ -2930,7 +2948,7 @@ static int knn_search_ivf2_impl(const float* bank, const float* inv_norm, const 
         c.blk_row0 = w.blk_row0; c.blk_stride = w.blk_stride; c.nblk = w.nblk; c.slotq = w.slotq;
         c.blk_nq = w.blk_nq; c.w_sparse = w_sparse; c.w_dense = w_dense;
         c.gmax = w.gmax; c.gmax_ld = 2 * stiles; c.item_off = w.sitem_off;
-        static const int cs_dbg = getenv("AURA_CS_DBG") ? atoi(getenv("AURA_CS_DBG")) : 0;
+        const int cs_dbg = cs_dbg_flags();
         c.dbg = cs_dbg;
         auto launch = [&](int mode) -> int {
             if (wg4) {
@@ -2972,7 +2990,7 @@ static int knn_search_ivf2_impl(const float* bank, const float* inv_norm, const 
         }
         c.gmax = nullptr; c.item_off = w.item_off;
         static int tm_left2 = 2;                             // AURA_CS_DBG bit 64: phase times of the first launches
-        const bool tm2 = (cs_dbg & 64) && tm_left2 > 0;
+        const bool tm2 = CS_TIMERS && (cs_dbg & 64) && tm_left2 > 0;
         if (tm2) {
             c.gmax = w.gmax;
             (void)hipMemsetAsync(w.gmax, 0, (size_t)cus * 8 * 8 * 4, s);
@@ -3033,7 +3051,7 @@ static int knn_search_ivf2_impl(const float* bank, const float* inv_norm, const 
             fprintf(stderr, "[ivf2] candidates %ld, invalid %ld\n", tot, bad);
         }
         static int rtm2_left = 2;                            // AURA_CS_DBG bit 128: refine phase times
-        const bool rtm2 = (cs_dbg & 128) && rtm2_left > 0;
+        const bool rtm2 = CS_TIMERS && (cs_dbg & 128) && rtm2_left > 0;
         if (rtm2) r.dbg_out = w.gmax;
         if ((rc = launch_refine_for(r, nqb, D, cus, s, w.heavy))) return rc;
         if (host_word && qb0 + w.qp >= nq) {                 // behind the call's last launch: flag + sequence number to the host
@@ -3319,6 +3337,12 @@ int aura_kmeans_assign(const float* bank, const float* centroids, float* cnorm2_
     a.row_begin = 0; a.row_end = N; a.tile_step = 1;
     a.qnorm2 = cnorm2_ws; a.assign_out = assign_out;
     return launch_scan<8, 1, 4>(a, MODE_ASSIGN, (N + 127) / 128, s);
+}
+
+int aura_debug_cs_flags(int flags) {
+    const int old = cs_dbg_flags();
+    if (flags >= 0) g_cs_dbg = flags;
+    return old;
 }
 
 int aura_profile_begin(int max_launches) {

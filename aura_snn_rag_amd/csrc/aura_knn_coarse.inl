@@ -430,6 +430,16 @@ __global__ __launch_bounds__(256) void coarse_threshold_kernel(const float* __re
 // QBT = 16-query column blocks per wave.  NW = 4 with QBT = 2 (round 3, inverted lists only): a workgroup of four
 // waves holds 128 query slots in 256 registers per wave and half the LDS -- TWO independent workgroups per CU, so
 // that one's MFMA phase overlaps the other's wait / issue / epilogue without a barrier between them.
+// Per-wave phase timers of the filter launch (AURA_CS_DBG bit 64) exist only in builds with -DAURA_CS_TIMERS=1
+// (tools/build_variant.sh): s_memrealtime is a scalar-memory instruction, and with it in the tile loop hipcc puts
+// "s_waitcnt lgkmcnt(0)" wherever its destination registers are reused -- which also waits for the loop's
+// inline-asm LDS reads, at a place that moves with every change of the register allocation (measured round 3:
+// the same source +-8 % on the launch).
+#ifndef AURA_CS_TIMERS
+#define AURA_CS_TIMERS 0
+#endif
+constexpr bool CS_TIMERS = AURA_CS_TIMERS != 0;
+
 template <int NW, int QBT> constexpr int cs_min_waves() { return (NW == 4 && QBT == 2) ? 2 : 1; }
 template <int NW, int QBT> constexpr int cs_cand_buf() { return (NW == 4 && QBT == 2) ? 512 : CS_BUF; }
 template <int KS, int MODE, bool SRC16, bool MASKED, bool IVF = false, int NW = 4, int QBT = 16 / NW>
@@ -576,10 +586,11 @@ __global__ __launch_bounds__(64 * NW, (cs_min_waves<NW, QBT>())) void coarse_sca
         wc[0] = 0; wc[1] = 0;
     };
 
-    const uint32_t t_kernel0 = (MODE == CS_MODE_FILTER && (a.dbg & 64)) ? (uint32_t)__builtin_amdgcn_s_memrealtime() : 0u;
+    const uint32_t t_kernel0 = (CS_TIMERS && MODE == CS_MODE_FILTER && (a.dbg & 64)) ? (uint32_t)__builtin_amdgcn_s_memrealtime() : 0u;
     int64_t c = lo;
     int blk_cur = -1;                                      // IVF: block of the previous segment
     while (c < hi) {
+        const uint32_t t_seg0 = (CS_TIMERS && MODE == CS_MODE_FILTER && (a.dbg & 64)) ? (uint32_t)__builtin_amdgcn_s_memrealtime() : 0u;
         int64_t qblk, j0, seg;
         if (IVF) {
             // The span [lo, hi) is in work units: item_off counts tiles x the block's weight (filter
@@ -737,9 +748,10 @@ __global__ __launch_bounds__(64 * NW, (cs_min_waves<NW, QBT>())) void coarse_sca
         int slot = 0;
         const int64_t n_int = n_steps;
         // AURA_CS_DBG bit 64: per-wave phase times (100 MHz ticks) into a.gmax (FILTER launches only)
-        const bool tm = MODE == CS_MODE_FILTER && (a.dbg & 64) && a.gmax != nullptr;
-        uint32_t tacc[6] = {0u, 0u, 0u, 0u, 0u, 0u};       // wait+barrier, check+issue, -, mma, write-out, epi
+        const bool tm = CS_TIMERS && MODE == CS_MODE_FILTER && (a.dbg & 64) && a.gmax != nullptr;
+        uint32_t tacc[6] = {0u, 0u, 0u, 0u, 0u, 0u};       // DMA wait, check+issue, segment set-up, mma (+ late issue), barrier, write-out + epilogue
         auto stamp = [&]() -> uint32_t { return tm ? (uint32_t)__builtin_amdgcn_s_memrealtime() : 0u; };
+        tacc[2] = stamp() - t_seg0;
         for (int64_t t = 0; t < n_int; ++t) {
             const uint32_t ts0 = stamp();
             const int par = (int)(t & 1);
@@ -773,6 +785,7 @@ __global__ __launch_bounds__(64 * NW, (cs_min_waves<NW, QBT>())) void coarse_sca
             }
             else if (wave == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(TPS * GL) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(TPS * NP) : "memory");
+            const uint32_t ts0b = stamp();
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             const uint32_t ts1 = stamp();
@@ -786,7 +799,13 @@ __global__ __launch_bounds__(64 * NW, (cs_min_waves<NW, QBT>())) void coarse_sca
                 for (int b = 0; b < NBc; ++b)
                     asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(eqr[b]) : "v"(ea), "n"(64 * b) : "memory");
             }
-            if (t + 2 < n_steps && !(a.dbg & 4)) issue_step(t + 2, (slot + 2) % NSLOT);
+            // Waves 4-7 of an 8-wave workgroup issue their share of step t + 2 BEHIND their MFMA loop (AURA_CS_DBG
+            // bit 4096 puts it back in front): an LDS-DMA instruction blocks its wave until the texture addresser
+            // takes it (0.4-0.8 us per step for the workgroup's 48 one-KiB requests); with the two waves of a SIMD
+            // in opposite orders one of them multiplies while the other one is blocked (-2.5 % of the launch,
+            // tools/ab_headline.py 0 4096).
+            const bool issue_late = NW == 8 && wave >= 4 && !(a.dbg & 4096);
+            if (!issue_late && t + 2 < n_steps && !(a.dbg & 4)) issue_step(t + 2, (slot + 2) % NSLOT);
             int cslot = 0;                                          // the 16-row slot this wave computes on
             int64_t ctile = 0;                                      // ... = tile j0 + ctile of the block
             bool work = false;
@@ -1005,6 +1024,7 @@ __global__ __launch_bounds__(64 * NW, (cs_min_waves<NW, QBT>())) void coarse_sca
             const uint32_t ts2 = stamp();
             const uint32_t ts3 = ts2;
             if (work) mma();
+            if (issue_late && t + 2 < n_steps && !(a.dbg & 4)) issue_step(t + 2, (slot + 2) % NSLOT);
             const uint32_t ts4 = stamp();
             if (MODE == CS_MODE_FILTER && fl_n > 0) {       // second step of the write-out (wave-uniform)
                 if (t + 2 >= n_steps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1025,7 +1045,6 @@ __global__ __launch_bounds__(64 * NW, (cs_min_waves<NW, QBT>())) void coarse_sca
                 wc[par ^ 1] = 0;
             }
 
-            const uint32_t ts5 = stamp();
             if (work) epi(ctile);
             if (RS == 3) {                                          // the step's second tile, same wave
                 set_tile(1);
@@ -1033,8 +1052,8 @@ __global__ __launch_bounds__(64 * NW, (cs_min_waves<NW, QBT>())) void coarse_sca
             }
             if (tm) {
                 const uint32_t ts6 = stamp();
-                tacc[0] += ts1 - ts0; tacc[1] += ts2 - ts1; tacc[2] += ts3 - ts2;
-                tacc[3] += ts4 - ts3; tacc[4] += ts5 - ts4; tacc[5] += ts6 - ts5;
+                tacc[0] += ts0b - ts0; tacc[1] += ts2 - ts1;
+                tacc[3] += ts4 - ts3; tacc[4] += ts1 - ts0b; tacc[5] += ts6 - ts4;
             }
             slot = (slot + 1) % NSLOT;
         }
@@ -1058,7 +1077,7 @@ __global__ __launch_bounds__(64 * NW, (cs_min_waves<NW, QBT>())) void coarse_sca
         if (wc[0] > 0 || wc[1] > 0) flush_all();
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }
-    if (MODE == CS_MODE_FILTER && (a.dbg & 64) && a.gmax != nullptr && lane == 0)   // whole-kernel time of this wave
+    if (CS_TIMERS && MODE == CS_MODE_FILTER && (a.dbg & 64) && a.gmax != nullptr && lane == 0)   // whole-kernel time of this wave
         a.gmax[((int64_t)blockIdx.x * 8 + wave) * 8 + 7] += (float)((uint32_t)__builtin_amdgcn_s_memrealtime() - t_kernel0);
 }
 
@@ -1297,7 +1316,7 @@ __device__ __forceinline__ void refine_one_query(const RefineArgs& a, const int 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int64_t D = a.D;
-    const bool tm = a.dbg_out != nullptr;
+    const bool tm = CS_TIMERS && a.dbg_out != nullptr;     // (phase timers: -DAURA_CS_TIMERS=1 builds only, see CS_TIMERS)
     uint32_t tst[7] = {0u, 0u, 0u, 0u, 0u, 0u, 0u};
     auto stamp = [&](int i) { if (tm) tst[i] = (uint32_t)__builtin_amdgcn_s_memrealtime(); };
     stamp(0);

@@ -193,6 +193,10 @@ int aura_knn_search_ivf(const float* bank, const float* inv_norm, const float* m
  * per-launch durations in milliseconds to the HOST array and returns how many it wrote
  * (negative AURA_E_* on error). */
 int aura_profile_begin(int max_launches);
+/* Tuning hook (tools/ab_headline.py): replaces the AURA_CS_DBG ablation flags of the scan kernels for the
+ * following calls (flags < 0: only read) and returns the previous value.  Non-zero flags switch kernel phases
+ * off or on for timing experiments; results are only valid with 0, the default. */
+int aura_debug_cs_flags(int flags);
 int aura_profile_end(float* ms_out_host, int max_out);
 /* Bank rows and queries scored by the most recent profiled main-scan launch (HOST pointers):
  * the units behind bench.py's algorithmic FLOP count, 2 * rows * nq * D per launch. */
