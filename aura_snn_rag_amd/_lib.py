@@ -89,6 +89,7 @@ SIGNATURES = {
                                         I64, P, P, U32, P]),
     "aura_profile_begin": (I, [I]),
     "aura_debug_cs_flags": (I, [I]),
+    "aura_debug_clock_mhz": (I, [P, I, P]),
     "aura_profile_end": (I, [P, I]),
     "aura_profile_last_scan": (I, [P, P]),
     "aura_profile_last_scan_kind": (I, []),

@@ -3339,6 +3339,23 @@ int aura_kmeans_assign(const float* bank, const float* centroids, float* cnorm2_
     return launch_scan<8, 1, 4>(a, MODE_ASSIGN, (N + 127) / 128, s);
 }
 
+// shader clock as the kernels see it: s_memtime ticks (shader clock) per s_memrealtime tick (100 MHz), one wave
+// spinning for `spin_us` microseconds.  Tuning hook (tools/ab_headline.py prints it beside the timings: the filter
+// launch's time is bimodal per process).
+__global__ void clock_probe_kernel(float* out, int spin_ticks) {
+    const uint64_t r0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_amdgcn_s_memtime();
+    uint64_t r1 = r0;
+    while ((int64_t)(r1 - r0) < (int64_t)spin_ticks) { __builtin_amdgcn_s_sleep(8); r1 = __builtin_amdgcn_s_memrealtime(); }
+    const uint64_t c1 = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) out[0] = (float)((double)(c1 - c0) / (double)(r1 - r0) * 100.0);   // MHz
+}
+
+int aura_debug_clock_mhz(float* out_dev, int spin_us, void* stream) {
+    if (!out_dev || spin_us < 1 || spin_us > 100000) return AURA_E_INVAL;
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), out_dev, spin_us * 100);
+    return check_launch();
+}
+
 int aura_debug_cs_flags(int flags) {
     const int old = cs_dbg_flags();
     if (flags >= 0) g_cs_dbg = flags;

@@ -473,8 +473,17 @@ __global__ __launch_bounds__(64 * NW, (cs_min_waves<NW, QBT>())) void coarse_sca
     const int64_t nqblk = (a.nq + 255) / 256;
     const int ivf_nblk = IVF ? a.nblk[0] : 0;
     const int64_t total = IVF ? (int64_t)a.item_off[ivf_nblk] : a.n_tiles * nqblk;
-    const int64_t lo = total * (int64_t)blockIdx.x / gridDim.x;
-    const int64_t hi = total * ((int64_t)blockIdx.x + 1) / gridDim.x;
+    int64_t lo = total * (int64_t)blockIdx.x / gridDim.x;
+    int64_t hi = total * ((int64_t)blockIdx.x + 1) / gridDim.x;
+    if (IVF && MODE == CS_MODE_SAMPLE && ivf_nblk <= (int)gridDim.x && !(a.dbg & 32768)) {
+        // Sample pass over inverted lists: every block has the same number of sample tiles, and a workgroup's
+        // set-up for a block (slot tables, 48 query fragments per lane, first tiles: three dependent latencies,
+        // ~10 us) is as long as four of its eight steps -- with no more blocks than workgroups each workgroup takes
+        // ONE whole block instead of the two halves an even split of the tiles gives it.
+        const int g = (int)blockIdx.x;
+        lo = g < ivf_nblk ? (int64_t)a.item_off[g] : 0;
+        hi = g < ivf_nblk ? (int64_t)a.item_off[g + 1] : 0;
+    }
 
     // Reader offsets inside a k-step block (lane = row lr, k-group lg), XOR-swizzled so that the 16
     // lanes of a ds_read_b128 phase hit 16 different bank quads:
@@ -668,32 +677,31 @@ __global__ __launch_bounds__(64 * NW, (cs_min_waves<NW, QBT>())) void coarse_sca
             }
             __syncthreads();
         }
-        // query part of the error bound: the accumulators start at +eq (FILTER: U) / -eq (SAMPLE: L)
-        if (SRC16) {
-            float* const s_eq = reinterpret_cast<float*>(csmem + LSLOTS * SLOT_BYTES + EQ_OFF);
-            if (tid < BLKQ) {
-                const int64_t q = qblk * BLKQ + tid;
-                const float v = a.eq[q < a.nq ? q : a.nq - 1];
-                s_eq[tid] = MODE == CS_MODE_FILTER ? v : -v;
-            }
-            __syncthreads();
+        // The block's slot tables -- the query part of the error bound (the accumulators start at +eq (FILTER: U) /
+        // -eq (SAMPLE: L)), the thresholds, the slots' queries -- are three independent loads: issued together and
+        // waited for once (one global latency in front of the fragment loads instead of three; the fragment
+        // addresses need the queries, and the thresholds' wait must not sit between the fragment loads).
+        float eqv = 0.0f;
+        uint32_t key[NBc];
+        if (SRC16 && tid < BLKQ) {
+            const int64_t q = qblk * BLKQ + tid;
+            eqv = a.eq[q < a.nq ? q : a.nq - 1];
         }
-        if (MODE == CS_MODE_FILTER) {                       // thresholds first: their wait must not
-            uint32_t key[NBc];                             // sit between the fragment loads
 #pragma unroll
-            for (int b = 0; b < NBc; ++b) {
-                const int q = qoff + 16 * b + lr;
-                key[b] = a.thr[q < a.nq ? q : a.nq - 1];
-            }
-#pragma unroll
-            for (int b = 0; b < NBc; ++b)                   // padding columns: NaN, "U >= NaN" never holds (U may be +inf)
-                thrf[b] = qoff + 16 * b + lr < a.nq ? ord_unkey(key[b]) : __builtin_nanf("");
-        } else {
-#pragma unroll
-            for (int b = 0; b < NBc; ++b) thrf[b] = INFINITY;
+        for (int b = 0; b < NBc; ++b) {
+            const int q = qoff + 16 * b + lr;
+            key[b] = MODE == CS_MODE_FILTER ? a.thr[q < a.nq ? q : a.nq - 1] : 0u;
         }
 #pragma unroll
         for (int b = 0; b < NBc; ++b) qid[b] = IVF ? a.slotq[qoff + 16 * b + lr] : 0;
+        if (SRC16) {
+            float* const s_eq = reinterpret_cast<float*>(csmem + LSLOTS * SLOT_BYTES + EQ_OFF);
+            if (tid < BLKQ) s_eq[tid] = MODE == CS_MODE_FILTER ? eqv : -eqv;
+            __syncthreads();
+        }
+#pragma unroll
+        for (int b = 0; b < NBc; ++b)                       // padding columns: NaN, "U >= NaN" never holds (U may be +inf)
+            thrf[b] = MODE == CS_MODE_FILTER ? (qoff + 16 * b + lr < a.nq ? ord_unkey(key[b]) : __builtin_nanf("")) : INFINITY;
 #pragma unroll
         for (int b = 0; b < NBc; ++b) {                     // (a column block without a query is never multiplied)
             // full scan: fragments laid out by slot, a fragment is one coalesced 1-KiB wave load; inverted lists:

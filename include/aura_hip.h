@@ -197,6 +197,9 @@ int aura_profile_begin(int max_launches);
  * following calls (flags < 0: only read) and returns the previous value.  Non-zero flags switch kernel phases
  * off or on for timing experiments; results are only valid with 0, the default. */
 int aura_debug_cs_flags(int flags);
+/* Tuning hook: the shader clock in MHz as a kernel sees it (s_memtime ticks per 100-MHz s_memrealtime tick over
+ * spin_us microseconds, 1..100000), written to out_dev[0] (device float). */
+int aura_debug_clock_mhz(float* out_dev, int spin_us, void* stream);
 int aura_profile_end(float* ms_out_host, int max_out);
 /* Bank rows and queries scored by the most recent profiled main-scan launch (HOST pointers):
  * the units behind bench.py's algorithmic FLOP count, 2 * rows * nq * D per launch. */

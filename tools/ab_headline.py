@@ -65,6 +65,10 @@ def main():
             res[f][0].append(e0.elapsed_time(e1) / a.steps)
             res[f][1].append(sum(buf[j] for j in range(n)) / max(n, 1))
     lib.aura_debug_cs_flags(0)
+    clk = torch.zeros(1, device=dev)
+    lib.aura_debug_clock_mhz(ctypes.c_void_p(clk.data_ptr()), 2000, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    print(f"shader clock (s_memtime / s_memrealtime over 2 ms, after the runs): {float(clk.item()):.0f} MHz")
     for f in a.flags:
         st, km = res[f]
         print(f"flags {f:6d}: step median {statistics.median(st):.4f} ms (min {min(st):.4f} max {max(st):.4f}); "
