@@ -385,6 +385,13 @@ def cpu_baseline(hf, q, k, now, n_sample, gpu_rows, gpu_scores, candidates):
                 tie[i] = bool((d[8] - d[7]) <= 2e-6 * d[7])
         sel = ~tie
         ex, n, ok = topk_equivalent(gpu_rows[:n_sample][sel], gpu_scores[:n_sample][sel], ref_r[sel], ref_s[sel])
+        if os.environ.get("AURA_BENCH_PARITY_DEBUG"):        # where and by how much the rows differ (stderr)
+            gr, gs = gpu_rows[:n_sample].cpu().long(), gpu_scores[:n_sample].cpu()
+            for i in torch.nonzero(~exact_q).flatten().tolist():
+                for p_ in torch.nonzero(gr[i] != ref_r[i]).flatten().tolist()[:4]:
+                    print(f"[parity] query {i} pos {p_}: gpu row {int(gr[i, p_])} score {float(gs[i, p_]):.9g} | "
+                          f"oracle row {int(ref_r[i, p_])} score {float(ref_s[i, p_]):.9g} | oracle next "
+                          f"{float(ref_s[i, min(p_ + 1, k - 1)]):.9g}", file=sys.stderr)
         parity = {"queries": int(n_sample), "index_exact": int(exact_q.sum()), "probe_near_ties": int(tie.sum()),
                   "within_tolerance_excluding_probe_near_ties": bool(ok),
                   "tolerance": "rows equal except where the oracle's own scores of the two rows differ by <= 2e-6; scores within 1e-5"}
@@ -506,6 +513,13 @@ def main():
     }
     if rank == 0 and world == 1:
         s_c, r_c = s, i
+        # CPU baseline and the GPU's parity on its sample FIRST, on the bank the headline ran on: the write
+        # benchmarks of the secondary section store the same random batch several times over (exact duplicate
+        # rows, i.e. exactly tied scores, whose order torch.topk and the GPU break differently: r03's first records
+        # read 51 of 64 index-exact queries for that reason alone; 64 of 64 on the untouched bank)
+        if not args.no_cpu_baseline:
+            s_h, r_h = hf.recall_batch(q[:args.cpu_queries].contiguous(), k=k, now=now, use_candidates=cand)
+            out["cpu_baseline"] = cpu_baseline(hf, q, k, now, args.cpu_queries, r_h, s_h, cand)
         if not args.no_secondary:
             sec = {}
             # exact recall on the same bank and queries, beside the headline
@@ -566,9 +580,6 @@ def main():
                           f"{hf.memory_count} x {D}, index on; r02: one workgroup, 15 us per row = 6.6e4 rows/s")
             sec["reference_semantics_write"] = rs
             out["secondary"] = sec
-        if not args.no_cpu_baseline:
-            s_h, r_h = hf.recall_batch(q[:args.cpu_queries].contiguous(), k=k, now=now, use_candidates=cand)
-            out["cpu_baseline"] = cpu_baseline(hf, q, k, now, args.cpu_queries, r_h, s_h, cand)
         if not args.no_secondary:
             del hf, sh
             torch.cuda.empty_cache()
