@@ -52,9 +52,12 @@ def main():
         print(f"bank {it}: kernel {statistics.median(ks):.4f} ms; " +
               "; ".join(f"{n} {p:#x} (mod 2M {p % (2 << 20):#x}, mod 1G {p % (1 << 30):#x})" for n, p in ptrs.items()),
               flush=True)
-        del hf, q, pick
-        gc.collect()
-        torch.cuda.empty_cache()
+        if os.environ.get("AURA_PROBE_KEEP"):            # keep every bank alive: the next one lands on other pages
+            spacers.append((hf, q, pick))
+        else:
+            del hf, q, pick
+            gc.collect()
+            torch.cuda.empty_cache()
 
 
 if __name__ == "__main__":
