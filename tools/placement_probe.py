@@ -52,6 +52,20 @@ def main():
         print(f"bank {it}: kernel {statistics.median(ks):.4f} ms; " +
               "; ".join(f"{n} {p:#x} (mod 2M {p % (2 << 20):#x}, mod 1G {p % (1 << 30):#x})" for n, p in ptrs.items()),
               flush=True)
+        if os.environ.get("AURA_PROBE_REPACK"):          # same buffers, other list boundaries: does the mode follow?
+            for seed in (8, 9, 10):
+                hf.rebuild_centroids(perm=torch.randperm(rows, generator=torch.Generator().manual_seed(seed)))
+                for _ in range(5):
+                    hf.recall_batch(q, k=k, now=now)
+                torch.cuda.synchronize()
+                lib.aura_profile_begin(30 * 16)
+                for _ in range(30):
+                    hf.recall_batch(q, k=k, now=now)
+                torch.cuda.synchronize()
+                buf = (ctypes.c_float * (30 * 16))()
+                n = lib.aura_profile_end(buf, 30 * 16)
+                print(f"bank {it} after a rebuild with seed {seed}: kernel {sum(buf[j] for j in range(n)) / max(n, 1):.4f} ms; "
+                      f"sorted_bf16 {hf._ivf.sorted_bf16.data_ptr():#x}", flush=True)
         if os.environ.get("AURA_PROBE_KEEP"):            # keep every bank alive: the next one lands on other pages
             spacers.append((hf, q, pick))
         else:
