@@ -109,3 +109,37 @@ print("WG4 OK")
     env = dict(os.environ, AURA_IVF_WG4="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "WG4 OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_tuning_hooks_keep_results_intact(dev):
+    """``aura_debug_cs_flags`` (in-process A/B of the scan kernels' switches) and ``aura_debug_clock_mhz``: the
+    result-preserving switches -- early LDS-DMA issue on waves 4-7 (4096), no row-split form (256), no two-tile
+    form (1024), an even split of the sample tiles (32768) -- give the default's rows and score bits; the flag word
+    is restored; the shader clock reads as a plausible number."""
+    import ctypes
+    from aura_snn_rag_amd import _lib
+    from aura_snn_rag_amd.core.hippocampal import HippocampalFormation
+    lib = _lib.load()
+    torch.manual_seed(3)
+    N, D, nq, k = 60_000, 256, 700, 16
+    hf = HippocampalFormation(feature_dim=D, max_memories=N, n_place_cells=8, n_time_cells=4, n_grid_cells=4,
+                              device="cuda", use_centroid_index=True)
+    hf.bulk_write(torch.randn(N, D, device=dev), rebuild=True)
+    now = float(hf.memory_metadata[0, 1].item()) + 5.0
+    q = torch.randn(nq, D, device=dev)
+    assert lib.aura_debug_cs_flags(-1) == 0
+    s0, r0 = hf.recall_batch(q, k=k, now=now)
+    try:
+        for flags in (4096, 256, 1024, 32768, 4096 | 256 | 1024 | 32768):
+            assert lib.aura_debug_cs_flags(flags) in (0, 4096, 256, 1024, 32768)
+            s1, r1 = hf.recall_batch(q, k=k, now=now)
+            assert torch.equal(r1, r0) and torch.equal(s1, s0), flags
+    finally:
+        lib.aura_debug_cs_flags(0)
+    assert lib.aura_debug_cs_flags(-1) == 0
+    clk = torch.zeros(1, device=dev)
+    assert lib.aura_debug_clock_mhz(ctypes.c_void_p(clk.data_ptr()), 500,
+                                    ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+    torch.cuda.synchronize()
+    assert 300.0 < float(clk.item()) < 4000.0, float(clk.item())
+    assert lib.aura_debug_clock_mhz(None, 500, None) != 0
