@@ -55,6 +55,7 @@ SIGNATURES = {
     "aura_kmeans_segment_means": (I, [P, P, P, P, P, I64, I64, I64, I, I, P]),
     "aura_kmeans_commit": (I, [P, P, P, P, I64, I, P]),
     "aura_addition_linear": (I, [P, P, P, P, I64, I64, I64, P]),
+    "aura_addition_linear_backward": (I, [P, P, P, P, P, I64, I64, I64, P]),
     "aura_gif_train_forward": (I, [P, P, P, P, P, P, F, I, F, F, I64, I64, I64, P]),
     "aura_gif_backward": (I, [P, P, P, P, P, P, F, I, F, F, I64, I64, I64, P]),
     "aura_gif_train_forward_bf16": (I, [P, P, P, P, P, P, F, I, F, F, I64, I64, I64, P]),

@@ -94,10 +94,16 @@ class EnhancedSpikingNeuron(nn.Module):
                 return self.core.forward_sequence(x_eff), {}, {}
             # [B, D] -> one timestep per neuron: [B, 1, D] sequence (ref :69-71)
             return self.core.forward_sequence(x_eff.unsqueeze(1)).squeeze(1), {}, {}
+        # LIF.  When the reference would build a graph (grad mode on and the current or the surrogate's slope
+        # requires grad) the steps go through the recording LIF step (aura_lif_train_forward / aura_lif_backward), one
+        # call per timestep as the reference's loop (:73-79); otherwise the whole sequence is one launch.
+        record = torch.is_grad_enabled() and (x_eff.requires_grad or self.core.slope.requires_grad)
         if is_seq:
-            return self.core.forward_sequence(x_eff), None, {}
-        with torch.no_grad():                       # the zone is a forward-only path
-            spikes, mem = self.core(x_eff)
+            if not record:
+                return self.core.forward_sequence(x_eff), None, {}
+            spikes = [self.core(x_eff[:, t])[0] for t in range(x_eff.shape[1])]
+            return torch.stack(spikes, dim=1), None, {}
+        spikes, mem = self.core(x_eff)
         return spikes, mem, {}
 
 

@@ -990,3 +990,18 @@ def addition_linear(x, weight_patterns, bias=None) -> torch.Tensor:
                                      x.shape[1], weight_patterns.shape[0], _stream()),
           "aura_addition_linear")
     return out
+
+
+def addition_linear_backward(x, weight_patterns, g_out, need_x: bool = True, need_w: bool = True):
+    """Gradients of ``addition_linear``: (g_x [B, in] or None, g_w [out, in] or None); abs -> sign, sign(0) = 0."""
+    _need(x, "x", torch.float32); _need(weight_patterns, "weight_patterns", torch.float32)
+    _need(g_out, "g_out", torch.float32)
+    B, IN = x.shape
+    OUT = weight_patterns.shape[0]
+    if weight_patterns.shape[1] != IN or tuple(g_out.shape) != (B, OUT):
+        raise ValueError("addition_linear_backward: shape mismatch")
+    g_x = torch.empty_like(x) if need_x else None
+    g_w = torch.empty_like(weight_patterns) if need_w else None
+    check(lib().aura_addition_linear_backward(_p(x), _p(weight_patterns), _p(g_out), _p(g_x), _p(g_w), B, IN, OUT,
+                                              _stream()), "aura_addition_linear_backward")
+    return g_x, g_w

@@ -467,6 +467,14 @@ int aura_addition_linear(const float* x, const float* weight_patterns, const flo
                          float* out, int64_t B, int64_t in_features, int64_t out_features,
                          void* stream);
 
+/* Backward of that projection, as autograd derives it from src/maths/addition_linear.py:50-64 (abs -> sign, with
+ * sign(0) = 0):  g_x[b][k] = -sum_o g_out[b][o] sgn(x[b][k] - w[o][k]),  g_w[o][k] = +sum_b g_out[b][o] sgn(x[b][k] -
+ * w[o][k]).  g_x [B][in] and g_w [out][in] are optional (NULL = not wanted); the bias gradient is g_out summed over
+ * the batch (the caller's reduction). */
+int aura_addition_linear_backward(const float* x, const float* weight_patterns, const float* g_out,
+                                  float* g_x, float* g_w, int64_t B, int64_t in_features,
+                                  int64_t out_features, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

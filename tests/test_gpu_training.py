@@ -327,3 +327,72 @@ def test_gif_module_trains_in_bf16(dev):
     y = ffn(torch.randn(2, 5, 32, device=dev, dtype=torch.bfloat16, requires_grad=True))
     y.float().sum().backward()
     assert all(p.grad is not None for p in ffn.parameters() if p.requires_grad)
+
+
+@pytest.mark.parametrize("B,IN,OUT,bias", [(5, 33, 17, True), (64, 256, 128, False), (130, 70, 200, True), (1, 4, 3, False)])
+def test_addition_linear_gradients(dev, B, IN, OUT, bias):
+    """AdditionLinear records autograd history when the reference would (it raised NotImplementedError for inputs
+    that require grad and silently dropped the templates' gradient until round 3): gradients of the input, the
+    templates and the bias against autograd over the oracle's restatement of addition_linear.py:50-64, exact
+    ties (x == w: sign(0) = 0) included."""
+    from aura_snn_rag_amd.maths.addition_linear import AdditionLinear
+    g = torch.Generator().manual_seed(B * 7 + IN)
+    lin = AdditionLinear(IN, OUT, bias=bias)
+    x = torch.randn(B, IN, generator=g) * 0.2
+    with torch.no_grad():
+        x[0, : min(IN, 3)] = lin.weight_patterns[min(OUT - 1, 1), : min(IN, 3)]      # exact ties
+        if bias:
+            lin.bias.copy_(torch.randn(OUT, generator=g))
+    wts = torch.randn(B, OUT, generator=g)
+    xo = x.clone().requires_grad_(True)
+    wo = lin.weight_patterns.detach().clone().requires_grad_(True)
+    bo = lin.bias.detach().clone().requires_grad_(True) if bias else None
+    ref_out = O.addition_linear(xo, wo, bo)
+    ref = torch.autograd.grad((ref_out * wts).sum(), [xo, wo] + ([bo] if bias else []))
+    lin = lin.to(dev)
+    xd = x.to(dev).requires_grad_(True)
+    out = lin(xd)
+    assert out.requires_grad and torch.allclose(out.detach().cpu(), ref_out.detach(), rtol=1e-5, atol=1e-4)
+    got = torch.autograd.grad((out * wts.to(dev)).sum(), [xd, lin.weight_patterns] + ([lin.bias] if bias else []))
+    for a, b, name in zip(got, ref, ("g_x", "g_w", "g_bias")):
+        scale = max(1.0, float(b.abs().max()))
+        assert torch.allclose(a.cpu(), b, rtol=1e-5, atol=2e-5 * scale), (name, float((a.cpu() - b).abs().max()))
+    # only the templates require grad (a frozen input): still recorded, no input gradient computed
+    out2 = lin(x.to(dev))
+    assert out2.requires_grad
+    (gw2,) = torch.autograd.grad((out2 * wts.to(dev)).sum(), [lin.weight_patterns])
+    assert torch.equal(gw2, got[1])
+    with torch.no_grad():
+        assert not lin(x.to(dev)).requires_grad
+
+
+def test_brain_zone_trains(dev):
+    """A zone with a LIF population sends gradients to both AdditionLinear projections, the LIF surrogate's slope
+    and the input (the reference's graph: addition_linear.py:50-64 + neuron.py:135-139 with the learnable
+    surrogate); the out-projection's template gradient equals autograd over the oracle given the same spikes."""
+    from aura_snn_rag_amd.base.snn_brain_zones import BrainZoneConfig, NeuromorphicBrainZone, SpikingNeuronConfig
+    torch.manual_seed(1)
+    cfgs = [SpikingNeuronConfig("lif", "s", "glu", 100.0, threshold=0.5, beta_decay=0.95)]
+    zone = NeuromorphicBrainZone(BrainZoneConfig(name="z", max_neurons=48, d_model=24, spiking_configs=cfgs)).to(dev)
+    with torch.no_grad():                                  # currents around the threshold: some neurons spike
+        zone.input_projection.weight_patterns.mul_(0.1)
+        zone.neuron_groups["lif"].homeo_i.fill_(1.5)
+    x = (torch.randn(9, 24, device=dev) * 0.05).requires_grad_(True)
+    wts = torch.randn(9, 24, device=dev)
+    out, info = zone(x)
+    assert out.requires_grad and 0.0 < info["avg_firing_rate"] < 1.0
+    params = [zone.input_projection.weight_patterns, zone.output_projection.weight_patterns,
+              zone.neuron_groups["lif"].core.slope]
+    got = torch.autograd.grad((out * wts).sum(), [x] + params)
+    assert all(t is not None and bool(torch.isfinite(t).all()) for t in got)
+    assert float(got[0].abs().sum()) > 0 and float(got[1].abs().sum()) > 0 and float(got[3].abs().sum()) > 0
+    # out-projection: oracle autograd given the zone's own spikes
+    with torch.no_grad():
+        zone.neuron_groups["lif"].core.reset_mem()
+        zin = zone.input_projection(x.detach())
+        spikes, _, _ = zone.neuron_groups["lif"](zin)
+    wo = zone.output_projection.weight_patterns.detach().cpu().clone().requires_grad_(True)
+    ref_out = O.addition_linear(spikes.cpu(), wo)
+    assert torch.allclose(out.detach().cpu(), ref_out.detach(), rtol=1e-5, atol=1e-4)
+    (ref_gw,) = torch.autograd.grad((ref_out * wts.cpu()).sum(), [wo])
+    assert torch.allclose(got[2].cpu(), ref_gw, rtol=1e-5, atol=2e-5 * max(1.0, float(ref_gw.abs().max())))
