@@ -646,6 +646,210 @@ __global__ __launch_bounds__(1024) void online_assign_fast_kernel(float* centroi
     if (tid < eff_k) counts[tid] = s_counts[tid];
 }
 
+// ---- phase B, decoupled form (round 3, second pass) ----
+// As the pipelined form above, without its barrier on the clear rows: wave 0 decides row i, publishes (winner, eta)
+// in a mailbox of ONL_WIN entries and a sequence number, applies its own 64 elements of the update and goes on to
+// row i + 1; the other fifteen waves wait for the sequence number (an LDS poll), apply theirs and prefetch.  A row
+// then costs max(decision, update) instead of decision + barrier + update.  Rows that need re-scoring meet at the
+// same barriers as before (every wave reads the same mailbox entry, so all of them take that branch), and one
+// barrier per ONL_WIN rows keeps the mailbox from being lapped.
+constexpr int ONL_WIN = 8;
+// minimum over the 64 lanes, in every lane: four DPP row rotations (each row of 16 lanes then holds its own
+// minimum), one lane read per row, three scalar-operand mins
+__device__ __forceinline__ float onl_wave_min(float v) {
+#define AURA_ROR_MIN(ctrl)                                                                                    \
+    v = fminf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false)))
+    AURA_ROR_MIN(0x128); AURA_ROR_MIN(0x124); AURA_ROR_MIN(0x122); AURA_ROR_MIN(0x121);
+#undef AURA_ROR_MIN
+    const int vi = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 48));
+    return fminf(fminf(r0, r1), fminf(r2, r3));
+}
+
+__global__ __launch_bounds__(1024) void online_assign_fast2_kernel(float* centroids, float* counts, int eff_k,
+                                                                  const float* __restrict__ feats,
+                                                                  const float* __restrict__ d0,
+                                                                  const float* __restrict__ xnorm,
+                                                                  const int32_t* __restrict__ pred,
+                                                                  int32_t* __restrict__ cid_out, int64_t n, int64_t D,
+                                                                  int vec4, float rel) {
+    extern __shared__ __attribute__((aligned(16))) float s_row[];   // [D] (re-scoring only)
+    __shared__ float s_delta[256], s_counts[256], s_fresh[256], s_xn[ONL_CHUNK];
+    __shared__ int s_cand[256], s_pred[ONL_CHUNK];
+    __shared__ int s_pub_best[ONL_WIN], s_pub_ncand[ONL_WIN];
+    __shared__ float s_pub_eta[ONL_WIN];
+    __shared__ int s_seq;                                    // rows published so far (row i's mailbox entry is valid once s_seq > i)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // Element e of every centroid row belongs to thread own0 + e.  With D <= 960 wave 0 owns nothing (own0 = 64): its
+    // loop is the decision chain alone, the fifteen other waves carry the update.
+    const int own0 = D <= 960 ? 64 : 0;
+    const int el = tid - own0;                               // this thread's element (if owner)
+    const bool owner = el >= 0 && el < D;
+    if (tid < 256) {
+        s_delta[tid] = 0.0f;
+        s_counts[tid] = tid < eff_k ? counts[tid] : 0.0f;
+    }
+    if (tid == 0) s_seq = 0;
+    for (int64_t i = tid; i < n; i += 1024) { s_pred[i] = pred[i]; s_xn[i] = xnorm[i]; }
+    __syncthreads();
+    auto prefetch = [&](OnlSlot& sl, int64_t row) {
+        if (row >= n) return;
+        const int p = s_pred[row];
+        sl.cid = p;
+        if (owner) {
+            sl.x = feats[row * D + el];
+            sl.cpre = centroids[(int64_t)p * D + el];
+        }
+        if (wave == 0) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = lane + 64 * u;
+                sl.d[u] = c < eff_k ? d0[row * 256 + c] : INFINITY;
+            }
+        }
+    };
+    auto commit = [&](int64_t i, int best, float dwin_up) {   // (one lane of wave 0)
+        const float cn = s_counts[best] + 1.0f;
+        s_counts[best] = cn;
+        const float eta = 1.0f / fmaxf(cn, 1.0f);
+        s_delta[best] += 1.0001f * (eta * dwin_up) + 3e-7f * (2.0f * s_xn[i] + dwin_up);
+        cid_out[i] = best;
+        s_pub_best[i & (ONL_WIN - 1)] = best;
+        s_pub_eta[i & (ONL_WIN - 1)] = eta;
+    };
+    int last1_id = -1, last2_id = -1;                         // centroids written in the previous two iterations ...
+    float last1_v = 0.0f, last2_v = 0.0f;                     // ... and this thread's element of what was written
+    auto step = [&](int64_t i, OnlSlot& sl) {
+        if (wave == 0) {
+            float lo[4], hi[4], dl[4];
+            float hmin = INFINITY;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = lane + 64 * u;
+                const bool valid = c < eff_k;
+                dl[u] = s_delta[c];
+                const float m = dl[u] == 0.0f ? 0.0f : sl.d[u] * rel + dl[u] * 1.0001f;
+                lo[u] = valid ? sl.d[u] - m : INFINITY;
+                hi[u] = valid ? sl.d[u] + m : INFINITY;
+                hmin = fminf(hmin, hi[u]);
+            }
+            hmin = onl_wave_min(hmin);                       // (DPP rotations + four lane reads: the ds_bpermute butterfly
+                                                             //  this replaces was six dependent LDS round trips per row)
+            unsigned long long cm[4];
+            int total = 0;
+            bool moved = false;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool cnd = lo[u] <= hmin;
+                cm[u] = __ballot(cnd);
+                total += (int)__popcll(cm[u]);
+                moved = moved || (cnd && dl[u] != 0.0f);
+            }
+            const bool any_moved = __ballot(moved) != 0ull;
+            if (total == 0) {
+                if (lane == 0) { s_pub_ncand[i & (ONL_WIN - 1)] = 1; commit(i, 0, 0.0f); }
+            } else if (total == 1) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (lo[u] <= hmin) { s_pub_ncand[i & (ONL_WIN - 1)] = 1; commit(i, lane + 64 * u, hi[u]); }
+            } else if (!any_moved) {
+                float bd = INFINITY;
+                int best = 0x7fffffff;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (lo[u] <= hmin && sl.d[u] < bd) { bd = sl.d[u]; best = lane + 64 * u; }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const float od = __shfl_xor(bd, off);
+                    const int ob = __shfl_xor(best, off);
+                    if (od < bd || (od == bd && ob < best)) { bd = od; best = ob; }
+                }
+                if (lane == 0) { s_pub_ncand[i & (ONL_WIN - 1)] = 1; commit(i, best, bd); }
+            } else {
+                int base = 0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (lo[u] <= hmin) {
+                        const int p = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(cm[u] >> 32),
+                                                  __builtin_amdgcn_mbcnt_lo((unsigned)cm[u], 0u));
+                        s_cand[p] = lane + 64 * u;
+                    }
+                    base += (int)__popcll(cm[u]);
+                }
+                if (lane == 0) s_pub_ncand[i & (ONL_WIN - 1)] = total;
+            }
+            // publish: the entry's fields were written by lanes of this wave, LDS keeps a wave's accesses in order
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) *(volatile int*)&s_seq = (int)(i + 1);
+        } else {
+            // the other waves follow wave 0's decisions through the mailbox: no barrier on the clear rows
+            int spins = 0;
+            while (*(volatile int*)&s_seq <= (int)i) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1 << 24)) break;              // (never in a correct run: do not hang the device)
+            }
+            asm volatile("" ::: "memory");
+        }
+        const int ncand = *(volatile int*)&s_pub_ncand[i & (ONL_WIN - 1)];
+        if (ncand > 1) {                                    // (workgroup-uniform) re-score the candidates
+            if (owner) s_row[el] = sl.x;
+            __threadfence_block();                          // every thread's centroid stores are done ...
+            __syncthreads();                                // ... before any wave reads whole rows
+            for (int ci = wave; ci < ncand; ci += 16) {
+                const float d = centroid_dist_wave(s_row, centroids + (int64_t)s_cand[ci] * D, D, lane, vec4 != 0);
+                if (lane == 0) s_fresh[ci] = d;
+            }
+            __syncthreads();
+            if (wave == 0) {
+                float bd = INFINITY;
+                int bi = 0x7fffffff;
+                for (int ci = lane; ci < ncand; ci += 64) {
+                    const float d = s_fresh[ci];
+                    if (d < bd) { bd = d; bi = ci; }
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const float od = __shfl_xor(bd, off);
+                    const int ob = __shfl_xor(bi, off);
+                    if (od < bd || (od == bd && ob < bi)) { bd = od; bi = ob; }
+                }
+                if (lane == 0) commit(i, s_cand[bi == 0x7fffffff ? 0 : bi], bd * (1.0f + rel));
+            }
+            __syncthreads();
+        }
+        const int best = *(volatile int*)&s_pub_best[i & (ONL_WIN - 1)];
+        const float eta = *(volatile float*)&s_pub_eta[i & (ONL_WIN - 1)];
+        const float one_m = 1.0f - eta;
+        if (owner) {
+            float c_old;
+            if (best == last1_id) c_old = last1_v;           // the newest value of that row is still in a register
+            else if (best == last2_id) c_old = last2_v;
+            else if (best == sl.cid) c_old = sl.cpre;        // prefetched behind every older store of this thread
+            else c_old = centroids[(int64_t)best * D + el];  // prediction missed: one L2 round trip
+            const float c_new = one_m * c_old + eta * sl.x;
+            centroids[(int64_t)best * D + el] = c_new;
+            last2_v = last1_v; last1_v = c_new;
+        }
+        last2_id = last1_id; last1_id = best;
+        prefetch(sl, i + 3);                                 // (issued behind this iteration's store)
+        // the mailbox has ONL_WIN entries: one barrier per window keeps wave 0 from lapping the slowest wave
+        if (((i + 1) & (ONL_WIN - 1)) == 0) __syncthreads();
+    };
+    OnlSlot a, b, c;
+    a.cid = b.cid = c.cid = -1;
+    prefetch(a, 0); prefetch(b, 1); prefetch(c, 2);
+    for (int64_t i = 0; i < n; i += 3) {
+        step(i, a);
+        if (i + 1 < n) step(i + 1, b);
+        if (i + 2 < n) step(i + 2, c);
+    }
+    __syncthreads();
+    if (tid < eff_k) counts[tid] = s_counts[tid];
+}
+
 __global__ __launch_bounds__(256) void bank_decay_kernel(float* meta, float factor, int64_t count) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < count) meta[i * 4] *= factor;
@@ -2565,8 +2769,10 @@ int aura_bank_write_online(float* bank, float* loc, float* meta, float* inv_norm
     int32_t* const pred = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(xnorm) + align_up(ch * 4, 256));
     int32_t* const cid = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(pred) + align_up(ch * 4, 256));
     static const bool simple = getenv("AURA_ONLINE_SIMPLE") != nullptr;   // A/B runs: the unpipelined phase B
+    static const bool v1 = getenv("AURA_ONLINE_V1") != nullptr;         // A/B runs: one barrier per row (the pipelined form)
     const bool fast = D <= 1024 && !simple;
-    if (fast && ensure_lds_attr(reinterpret_cast<const void*>(online_assign_fast_kernel), 8 * 1024)) return AURA_E_LAUNCH;
+    if (fast && (ensure_lds_attr(reinterpret_cast<const void*>(online_assign_fast_kernel), 8 * 1024) ||
+                 ensure_lds_attr(reinterpret_cast<const void*>(online_assign_fast2_kernel), 8 * 1024))) return AURA_E_LAUNCH;
     // fp slack of a computed distance against the exact one, both ways: 2 x (chain of D/64 fmaf + 6 butterfly
     // adds + subtraction, square root) x 2^-24, with a factor 2 in hand
     const float rel = 4.0f * ((float)((D + 63) / 64) + 10.0f) * 5.9604645e-8f;
@@ -2579,8 +2785,10 @@ int aura_bank_write_online(float* bank, float* loc, float* meta, float* inv_norm
         if (fast) {
             hipLaunchKernelGGL(online_pred_kernel, dim3((unsigned)((nr + 3) / 4)), dim3(256), 0, s, d0, eff_k, nr, pred);
             if ((rc = check_launch())) return rc;
-            hipLaunchKernelGGL(online_assign_fast_kernel, dim3(1), dim3(1024), lds, s, centroids, centroid_counts, eff_k,
-                               feats + r0 * D, d0, xnorm, pred, cid, nr, D, vec4, rel);
+            if (v1) hipLaunchKernelGGL(online_assign_fast_kernel, dim3(1), dim3(1024), lds, s, centroids, centroid_counts,
+                                       eff_k, feats + r0 * D, d0, xnorm, pred, cid, nr, D, vec4, rel);
+            else hipLaunchKernelGGL(online_assign_fast2_kernel, dim3(1), dim3(1024), lds, s, centroids, centroid_counts,
+                                    eff_k, feats + r0 * D, d0, xnorm, pred, cid, nr, D, vec4, rel);
             if ((rc = check_launch())) return rc;
             hipLaunchKernelGGL(online_cid_scatter_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, s, meta,
                                slots + r0, cid, nr);
