@@ -654,6 +654,10 @@ __global__ __launch_bounds__(1024) void online_assign_fast_kernel(float* centroi
 // same barriers as before (every wave reads the same mailbox entry, so all of them take that branch), and one
 // barrier per ONL_WIN rows keeps the mailbox from being lapped.
 constexpr int ONL_WIN = 8;
+#ifndef AURA_ONL_POLL_SLEEP
+#define AURA_ONL_POLL_SLEEP 2
+#endif
+constexpr int ONL_POLL_SLEEP = AURA_ONL_POLL_SLEEP;   // s_sleep units (64 clocks) between two polls of the sequence number
 // minimum over the 64 lanes, in every lane: four DPP row rotations (each row of 16 lanes then holds its own
 // minimum), one lane read per row, three scalar-operand mins
 __device__ __forceinline__ float onl_wave_min(float v) {
@@ -788,7 +792,7 @@ __global__ __launch_bounds__(1024) void online_assign_fast2_kernel(float* centro
             // the other waves follow wave 0's decisions through the mailbox: no barrier on the clear rows
             int spins = 0;
             while (*(volatile int*)&s_seq <= (int)i) {
-                __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_s_sleep(ONL_POLL_SLEEP);
                 if (++spins > (1 << 24)) break;              // (never in a correct run: do not hang the device)
             }
             asm volatile("" ::: "memory");
