@@ -41,6 +41,8 @@ CASES = [
     (200, 50, 200, False, False),       # D % 4 != 0 (scalar loads), fewer than 256 centroids
     (5000, 128, 256, False, False),     # more than one phase A / phase B chunk
     (400, 1024, 17, True, False),
+    (300, 960, 256, False, False),      # the widest row whose elements all live on waves 1-15 (wave 0 only decides)
+    (120, 964, 64, False, False),       # one step wider: wave 0 owns elements again
 ]
 
 
