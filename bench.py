@@ -421,10 +421,23 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        # RCCL prints a version banner ("RCCL version : ...", five lines) on STDOUT when its first communicator comes
+        # up; the contract is ONE JSON line there.  File descriptor 1 points at stderr until the communicator exists.
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
+            t0_ = torch.zeros(1, device=dev)
+            dist.all_reduce(t0_)
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     from aura_snn_rag_amd import _lib
     from aura_snn_rag_amd.sharded import ShardedHippocampus
