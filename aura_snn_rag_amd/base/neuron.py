@@ -223,7 +223,9 @@ class VectorizedLIFNeuron(nn.Module):
     def reset_mem(self):
         self.mem = None
 
-    def _dtype(self, x: torch.Tensor) -> torch.dtype:
+    def _dtype(self, x: torch.Tensor, mem: Optional[torch.Tensor]) -> torch.dtype:
+        """The dtype the reference's eager ops would compute this call in: the promotion of the input, the
+        buffers and the carried membrane (``mem``: None = none carried, i.e. zeros of the input's dtype)."""
         who = "VectorizedLIFNeuron"
         if not x.is_cuda:
             raise ops.AuraDeviceError(f"{who}: input is on {x.device}; the neuron loops run only as HIP "
@@ -234,7 +236,7 @@ class VectorizedLIFNeuron(nn.Module):
             if t.dtype not in (torch.float32, torch.bfloat16):
                 raise TypeError(f"{who}: {n} is {t.dtype}; fp32 and bf16 are implemented")
         dt = x.dtype
-        for t in (self.beta, self.threshold) + (() if self.mem is None or self.mem.shape != x.shape else (self.mem,)):
+        for t in (self.beta, self.threshold) + (() if mem is None else (mem,)):
             dt = torch.promote_types(dt, t.dtype)
         return dt
 
@@ -246,21 +248,21 @@ class VectorizedLIFNeuron(nn.Module):
                                             (self.mem is not None and self.mem.requires_grad))
 
     def forward(self, input_: torch.Tensor):
-        dt = self._dtype(input_)
+        carried = self.mem if (self.mem is not None and self.mem.shape == input_.shape) else None
+        dt = self._dtype(input_, carried)
         beta, thr = self._consts(dt)
         if self._wants_grad(input_):
             x = input_.to(dt)
-            if self.mem is None or self.mem.shape != x.shape:
-                self.mem = torch.zeros_like(x)
+            mem = torch.zeros_like(x) if carried is None else carried.to(dt)
             # the surrogate's slope keeps its own dtype in the reference (it only enters the backward): widen or
             # narrow it for the kernel through autograd so that its gradient comes back in the parameter's dtype
-            spk, self.mem = LifStepFunction.apply(x, self.mem.to(dt), beta, thr, self.slope.to(dt))
+            spk, self.mem = LifStepFunction.apply(x, mem, beta, thr, self.slope.to(dt))
             return spk, self.mem
         x = input_.detach().to(dt).contiguous()
-        if self.mem is None or self.mem.shape != x.shape:
+        if carried is None:
             self.mem = torch.zeros_like(x)
-        elif self.mem.requires_grad or self.mem.dtype != dt or not self.mem.is_contiguous():
-            self.mem = self.mem.detach().to(dt).contiguous().clone()
+        elif carried.requires_grad or carried.dtype != dt or not carried.is_contiguous():
+            self.mem = carried.detach().to(dt).contiguous().clone()
         spk = torch.empty_like(x)
         rows = x.numel() // self.size if self.size else 0
         ops.lif_run(x.view(rows, 1, self.size), spk.view(rows, 1, self.size),
@@ -271,19 +273,14 @@ class VectorizedLIFNeuron(nn.Module):
         if x_seq.dim() != 3:
             raise ValueError("forward_sequence expects [B, T, size]")
         B, T, _ = x_seq.shape
-        if self.mem is not None and self.mem.shape != (B, self.size):
-            self.mem = None
-        saved, self.mem = self.mem, None                   # _dtype() compares mem's shape with a single step's
-        dt = self._dtype(x_seq)
-        if saved is not None:
-            dt = torch.promote_types(dt, saved.dtype)
+        carried = self.mem if (self.mem is not None and tuple(self.mem.shape) == (B, self.size)) else None
+        dt = self._dtype(x_seq, carried)
         beta, thr = self._consts(dt)
         x = x_seq.detach().to(dt).contiguous()
-        if saved is None:
+        if carried is None:
             self.mem = torch.zeros(B, self.size, device=x.device, dtype=dt)
-        else:
-            self.mem = saved.detach().to(dt).contiguous().clone() if (saved.requires_grad or saved.dtype != dt or
-                                                                      not saved.is_contiguous()) else saved
+        elif carried.requires_grad or carried.dtype != dt or not carried.is_contiguous():
+            self.mem = carried.detach().to(dt).contiguous().clone()
         spikes = torch.empty_like(x)
         ops.lif_run(x, spikes, self.mem, beta, thr)
         return spikes
