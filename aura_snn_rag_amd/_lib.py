@@ -86,6 +86,7 @@ SIGNATURES = {
                                         I64, P, I, I, P, P]),
     "aura_host_word_alloc": (I, [P]),
     "aura_host_word_free": (I, [P]),
+    "aura_signal_flag": (I, [P, P, U32, P]),
     "aura_knn_search_ivf2_signal": (I, [P, P, P, P, P, P, P, P, P, P, I64, I64, P, F, I64, I64, I, P, I, P, I32, P, P, P,
                                         I64, P, P, U32, P]),
     "aura_profile_begin": (I, [I]),

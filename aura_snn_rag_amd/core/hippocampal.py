@@ -79,6 +79,8 @@ class _EpisodicView(Mapping):
 
 # AURA_NO_HOST_WORD=1: read the recall's flag with a device-to-host copy instead of polling the completion word (A/B runs)
 _NO_HOST_WORD = os.environ.get("AURA_NO_HOST_WORD") is not None
+# AURA_EXCHANGE_ONCE=1: a sharded recall combines only the sampled bounds (stage 1), not the candidates' (A/B runs)
+_EXCHANGE_TWICE = os.environ.get("AURA_EXCHANGE_ONCE") is None
 
 
 class _IvfState:
@@ -593,7 +595,8 @@ class HippocampalFormation(nn.Module):
         inverted-list path then skips its own probe; other paths ignore it).  ``bound_exchange``
         (``sharded.ShardedHippocampus``): ``(fn, parts)`` -- the inverted-list recall runs in two stages per pass of
         at most 8192 queries and ``fn(bounds [n, 2]) -> bound [n]`` combines every shard's sampled bounds in
-        between (a collective: it is called exactly ``ceil(nq / 8192)`` times whatever path this bank takes)."""
+        between (a collective: it is called exactly ``2 ceil(nq / 8192)`` times -- sampled bounds, then the filtered
+        candidates' bounds; once per pass with ``AURA_EXCHANGE_ONCE`` -- whatever path this bank takes)."""
         self._last_flag = None                        # set only by a candidate-mode recall that read its flag
 
         def drain_exchanges(nq_: int) -> None:
@@ -601,8 +604,9 @@ class HippocampalFormation(nn.Module):
             if bound_exchange is not None:
                 step = ops.Ivf2Staged.MAX_QUERIES
                 for lo_ in range(0, nq_, step):
-                    bound_exchange[0](torch.full((min(step, nq_ - lo_), 2), -3.0e38, dtype=torch.float32,
-                                                 device=self.device))
+                    for _ in range(2 if _EXCHANGE_TWICE else 1):     # (sampled bounds, then the candidates' bounds)
+                        bound_exchange[0](torch.full((min(step, nq_ - lo_), 2), -3.0e38, dtype=torch.float32,
+                                                     device=self.device))
         if self.memory_count == 0:
             drain_exchanges(queries.shape[0])
             z = torch.empty(queries.shape[0], 0, device=self.device)
@@ -650,6 +654,14 @@ class HippocampalFormation(nn.Module):
             if ivf is not None and bound_exchange is not None:
                 scores, rows, ovf = self._recall_ivf2_exchanged(q, kk, now, nprobe, ivf, probe_ids, bound_exchange)
                 exchanged = True
+                if check_overflow and not _NO_HOST_WORD:
+                    # the flag through a host-mapped word behind the last stage (as the plan's path below): polled,
+                    # not synchronised for
+                    hw = getattr(ivf, "_host_flag", None)
+                    if hw is None:
+                        hw = ivf._host_flag = ops.HostFlag(q.device)
+                    hw.signal(ovf)
+                    flag_of = hw.wait
             elif ivf is not None:
                 # large banks / large batches: inverted lists on the two-stage scan (every probed list is
                 # streamed once per 2048 queries from the list-sorted bf16 shadow); same rows and score bits
@@ -714,21 +726,39 @@ class HippocampalFormation(nn.Module):
         k2 = max(1, -(-kk // max(int(parts), 1)))
         rowc = self._ivf_row_constants(ivf, now)
         step = ops.Ivf2Staged.MAX_QUERIES
-        out_s, out_i, flag = [], [], None
-        for lo in range(0, q.shape[0], step):
-            hi = min(q.shape[0], lo + step)
-            st = ops.Ivf2Staged(self.memory_features, self._inv_norm, self.memory_metadata, q[lo:hi].contiguous(), kk, now,
+        nq = q.shape[0]
+        # results land in ONE pair of tensors (each pass writes its slice); the constructor's tensor checks run once
+        # per bank layout, not once per pass and call: the staged recall of a sharded bank is host-bound otherwise
+        # (eight ranks: 2 passes x 5 Python-level steps per call against ~1.1 ms of kernels)
+        out_s = torch.empty(nq, kk, dtype=torch.float32, device=q.device)
+        out_i = torch.empty(nq, kk, dtype=torch.int32, device=q.device)
+        sig = (id(self.memory_features), id(self.memory_metadata), id(self.centroids), id(ivf.sorted_bf16), id(rowc),
+               ivf.n_sorted, int(kk), int(nprobe))
+        validated = getattr(ivf, "_staged_sig", None) == sig
+        flag = None
+        for lo in range(0, nq, step):
+            hi = min(nq, lo + step)
+            st = ops.Ivf2Staged(self.memory_features, self._inv_norm, self.memory_metadata, q[lo:hi], kk, now,
                                 self.centroids, nprobe, ivf.sorted_bf16, self._rho, ivf.sorted_rows, ivf.pad_off,
                                 ivf.list_len, n_sorted=ivf.n_sorted, lists_flag=ivf.flag,
-                                probe_ids=None if probe_ids is None else probe_ids[lo:hi].contiguous(),
-                                row_constants=rowc)
+                                probe_ids=None if probe_ids is None else probe_ids[lo:hi],
+                                row_constants=rowc, out=(out_s[lo:hi], out_i[lo:hi]), validated=validated)
+            ivf._staged_sig = sig
+            validated = True
             bound = fn(st.stage1(k2))
-            s_, i_, f_ = st.stage2(bound.contiguous())
-            if hi - lo == q.shape[0]:
-                return s_, i_, f_
-            out_s.append(s_.clone()); out_i.append(i_.clone())
+            if _EXCHANGE_TWICE:
+                # second exchange, on the FILTERED candidates' bounds: the k-th largest lower bound over the shards'
+                # candidates (max over shards of each one's k-th, min over shards of each one's ceil(k / S)-th) is
+                # close to the global k-th best score itself, so a shard re-scores ~k / S + gap rows per query
+                # instead of k + gap -- the refine is half of a shard's share at 8 shards
+                bound2 = fn(st.stage2_bounds(bound, k2))
+                _, _, f_ = st.stage3(torch.maximum(bound2, bound))
+            else:
+                _, _, f_ = st.stage2(bound)
+            if hi - lo == nq:
+                return out_s, out_i, f_
             flag = f_.clone() if flag is None else flag.bitwise_or_(f_)   # stage 1 of the next pass resets the flag
-        return torch.cat(out_s), torch.cat(out_i), flag
+        return out_s, out_i, flag
 
     def probe(self, queries: torch.Tensor) -> Optional[torch.Tensor]:
         """The centroid probes of ``queries`` ([nq, 8] int32, the 8 nearest of the 256 centroid rows in

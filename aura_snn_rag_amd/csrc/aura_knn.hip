@@ -3076,7 +3076,8 @@ static int knn_search_ivf2_impl(const float* bank, const float* inv_norm, const 
     if (n_sorted > 0x7ffffff0LL || (n_sorted & 15)) return AURA_E_INVAL;
     const Ivf2Workspace w = carve_ivf2(workspace, n_sorted, nq, k);
     if (w.bytes > workspace_bytes) return AURA_E_INVAL;
-    if (stg != 0 && (nq > w.qp || !bounds || stg < 0 || stg > 2 || k2 < 0 || k2 > k)) return AURA_E_INVAL;
+    if (stg != 0 && (nq > w.qp || !bounds || stg < 0 || stg > 4 || k2 < 0 || k2 > k)) return AURA_E_INVAL;
+    const bool stage_a = stg <= 1;                           // query prep .. thresholds run in this call (stages 0, 1)
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int KS = D <= 256 ? 8 : (D <= 512 ? 16 : 24);
     const float e_fix = aura_e_fix((float)D);                // see aura_knn_coarse.inl
@@ -3113,7 +3114,7 @@ static int knn_search_ivf2_impl(const float* bank, const float* inv_norm, const 
     // creations and the cross-stream waits cost more than the 35 us they hide.)
     const float4* rowc = rowc_cached;
     if (!rowc) {
-        if (stg != 2) {
+        if (stage_a) {
             hipLaunchKernelGGL(ivf2_rowc_kernel, dim3((unsigned)((n_sorted + 255) / 256)), dim3(256), 0, s,
                                meta, rho, sorted_rows, n_sorted, now, (float)D, w.rowc);
             if ((rc = check_launch())) return rc;
@@ -3123,7 +3124,7 @@ static int knn_search_ivf2_impl(const float* bank, const float* inv_norm, const 
     for (int64_t qb0 = 0; qb0 < nq; qb0 += w.qp) {
         const int nqb = (int)((nq - qb0) < w.qp ? (nq - qb0) : w.qp);
         const float* qptr = queries + qb0 * D;
-        if (stg != 2) {
+        if (stage_a) {
         // per query: 1/||q||, bf16 fragments, eq; resets of the pass (per-list counters, qslot, the call's flag)
         hipLaunchKernelGGL(ivf2_qprep_kernel, dim3((unsigned)((nqb + 1 + 3) / 4)), dim3(256), 0, s,
                            qptr, (int64_t)nqb, D, KS, w.qhat, w.inv_q, w.eq_q, w.qslot, w.lq_cnt,
@@ -3177,7 +3178,7 @@ static int knn_search_ivf2_impl(const float* bank, const float* inv_norm, const 
             if (KS == 16) return launch_coarse_ivf<16, 8>(c, mode, cus, s);
             return launch_coarse_ivf<24, 8>(c, mode, cus, s);
         };
-        if (stg != 2) {
+        if (stage_a) {
         if ((rc = launch(CS_MODE_SAMPLE))) return rc;
         stage("sample scan");
         {
@@ -3193,13 +3194,14 @@ static int knn_search_ivf2_impl(const float* bank, const float* inv_norm, const 
         if ((rc = check_launch())) return rc;
         stage("threshold");
         if (stg == 1) return AURA_OK;
-        } else {
+        } else if (stg != 3) {
             // the caller's bound (e.g. combined over the shards of a row-sharded bank) tightens the thresholds
             hipLaunchKernelGGL(ivf2_raise_thr_kernel, dim3((unsigned)((((int64_t)ivf2_maxblk(w.qp, bsh) << bsh) + 255) / 256)), dim3(256), 0, s,
                                w.slotq, w.nblk, bounds, w.thr, bsh);
             if ((rc = check_launch())) return rc;
             stage("raise thresholds");
         }
+        if (stg != 3) {                                      // (stage 3: the candidates of stage 4 are in the workspace)
         c.gmax = nullptr; c.item_off = w.item_off;
         static int tm_left2 = 2;                             // AURA_CS_DBG bit 64: phase times of the first launches
         const bool tm2 = CS_TIMERS && (cs_dbg & 64) && tm_left2 > 0;
@@ -3233,6 +3235,7 @@ static int knn_search_ivf2_impl(const float* bank, const float* inv_norm, const 
             fprintf(stderr, "[ivf2] rows in lists probed by <=64 / <=128 / <=256 / >256 queries: %ld / %ld / %ld / %ld; row reads %ld\n",
                     rows_le64, rows_le128, rows_le256, rows_more, reads);
         }
+        }
 
         RefineArgs r{};
         r.bank = bank; r.inv_norm = inv_norm; r.meta = meta; r.queries = qptr; r.inv_q = w.inv_q;
@@ -3240,6 +3243,14 @@ static int knn_search_ivf2_impl(const float* bank, const float* inv_norm, const 
         r.rho = rho; r.eq = w.eq_q; r.e_fix = e_fix; r.eq_worst = coarse_eq_worst((float)D);
         r.cand_scores = w.cand_scores; r.cand_idx = w.cand_idx; r.cap = w.cap; r.idx_base = idx_base;
         r.out_scores = out_scores + qb0 * k; r.out_idx = out_idx + qb0 * k; r.overflow = overflow_out;
+        if (stg == 4) {
+            // stage 4 ends here: the candidates' k-th and k2-th largest lower bounds per query, for the caller to
+            // combine over its shards; stage 3 re-scores against the combined bound
+            hipLaunchKernelGGL(coarse_refine_bounds_kernel, dim3((unsigned)((nqb + RF_THREADS / 64 - 1) / (RF_THREADS / 64))),
+                               dim3(RF_THREADS), 0, s, r, nqb, k2, bounds);
+            return check_launch();
+        }
+        if (stg == 3) r.t2_ext = bounds;
         if (trace) {                                         // candidate lists with row ids outside the bank
             (void)hipStreamSynchronize(s);
             std::vector<int32_t> hc((size_t)nqb * CNT_STRIDE), hi((size_t)nqb * w.cap);
@@ -3331,6 +3342,16 @@ int aura_host_word_alloc(void** host_word_out) {
     return AURA_OK;
 }
 
+// flag + sequence number to a host word behind whatever the stream holds (the staged recall's last stage, a chain of
+// passes): the caller polls host_word[1] == host_seq instead of synchronising the stream -- a blocking wait on a
+// ~1 ms stream costs the host 1-2 ms on this runtime (interrupt wake-up), the poll costs what the GPU takes
+int aura_signal_flag(const int32_t* flag_dev, uint32_t* host_word, uint32_t host_seq, void* stream) {
+    if (!host_word) return AURA_E_INVAL;
+    hipLaunchKernelGGL(ivf2_signal_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), flag_dev, host_word,
+                       host_seq);
+    return check_launch();
+}
+
 int aura_host_word_free(void* host_word) {
     if (!host_word) return AURA_OK;
     return hipHostFree(host_word) == hipSuccess ? AURA_OK : AURA_E_LAUNCH;
@@ -3360,7 +3381,7 @@ int aura_knn_search_ivf2_staged(const float* bank, const float* inv_norm, const 
                                 int k, const float* centroids, int nprobe, const int32_t* probe_ids, int32_t idx_base,
                                 float* out_scores, int32_t* out_idx, void* workspace, int64_t workspace_bytes,
                                 int32_t* overflow_out, int stage, int k2, float* bounds, void* stream) {
-    if (stage != 1 && stage != 2) return AURA_E_INVAL;
+    if (stage < 1 || stage > 4) return AURA_E_INVAL;        // 1, 2, 4 + 3 (see the header)
     if (reinterpret_cast<uintptr_t>(row_constants) & 15) return AURA_E_ALIGN;
     return knn_search_ivf2_impl(bank, inv_norm, meta, sorted_bf16, rho, sorted_rows, pad_off, list_len, lists_flag,
                                 n_sorted, N, queries, now, D, nq, k, centroids, nprobe, idx_base, out_scores, out_idx,

@@ -1113,6 +1113,9 @@ struct RefineArgs {
     int32_t* out_idx;
     int32_t* overflow;
     float* dbg_out;             // AURA_CS_DBG bit 128: [nq][8] phase times (100 MHz ticks), n, S
+    const float* t2_ext;        // optional [nq]: a lower bound of every query's k-th best score known from OUTSIDE this
+                                // bank (the shards of a row-sharded bank combine theirs, coarse_refine_bounds_kernel):
+                                // candidates with U below it cannot be in the caller's top k and are not re-scored
     int32_t* heavy;             // optional [1 + nq]: heavy[0] = number of queries coarse_refine_wave_kernel left to the
                                 // workgroup-per-query kernel (zero before that launch), heavy[1..] = those queries
 };
@@ -1198,6 +1201,7 @@ __device__ __forceinline__ void refine_wave_body(const RefineArgs& a, int nq) {
             if (c >= a.k) t2 = cand;
         }
     }
+    if (a.t2_ext) { const uint32_t e = ord_key(a.t2_ext[q]); t2 = e > t2 ? e : t2; }
     // ---- survivors: U >= T2, compacted in candidate order ----
     int S = 0;
 #pragma unroll
@@ -1216,7 +1220,8 @@ __device__ __forceinline__ void refine_wave_body(const RefineArgs& a, int nq) {
         if (lane == 0) a.heavy[1 + atomicAdd(a.heavy, 1)] = q;
         return;
     }
-    if (lane == 0 && S == 0 && a.overflow) atomicOr(a.overflow, AURA_KNN_FLAG_NO_CANDIDATES);   // (not an overflow)
+    // (under an external bound a query whose candidates were all pruned HAD candidates: the flag is for n == 0)
+    if (lane == 0 && S == 0 && (n == 0 || !a.t2_ext) && a.overflow) atomicOr(a.overflow, AURA_KNN_FLAG_NO_CANDIDATES);   // (not an overflow)
     // ---- the query, zero padded to Dpad ----
     for (int64_t i = lane; i < Dpad; i += 64) s_q[i] = i < D ? a.queries[(int64_t)q * D + i] : 0.0f;
     __builtin_amdgcn_wave_barrier();
@@ -1307,6 +1312,69 @@ __global__ __launch_bounds__(RF_THREADS, 4) void coarse_refine_wave6_kernel(cons
     refine_wave_body<6, 8>(a, nq);
 }
 
+// ---- the candidates' own bounds, for a row-sharded bank (round 3): per query T_k and T_k2, the k-th and the
+//      k2-th largest LOWER bound L = U - 2 err among this bank's candidates (k2 = ceil(k / shards)).  The shards
+//      combine them -- max over shards of T_k, min over shards of T_k2: S disjoint shards x k2 rows each are k rows
+//      -- into a lower bound of the GLOBAL k-th best score, far tighter than the sampled one of stage 1 (it comes
+//      from the filtered candidates, i.e. from exact bounds of the best rows), and the refine launches re-score
+//      only candidates whose U reaches it (RefineArgs::t2_ext): ~k / S + gap survivors per shard instead of k + gap.
+//      One wave per query, candidates in registers as in refine_wave_body; a list too long for that (more than
+//      512 candidates) reports -inf, the neutral element of both reductions.  out [nq][2]. ----
+__global__ __launch_bounds__(RF_THREADS) void coarse_refine_bounds_kernel(const RefineArgs a, int nq, int k2,
+                                                                          float* __restrict__ out) {
+    constexpr int RW_CAND = 8;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int q = blockIdx.x * (RF_THREADS / 64) + wave;
+    if (q >= nq) return;
+    const int n = a.cnt[(int64_t)q * CNT_STRIDE];
+    const int capn = a.cap < RF_CAP ? a.cap : RF_CAP;
+    float tk = -INFINITY, tk2 = -INFINITY;
+    if (n <= capn && n <= RW_CAND * 64 && n > 0) {
+        const int nj = (n + 63) >> 6;
+        const float eqq = a.rho ? a.eq[q] : 0.0f;
+        float cu[RW_CAND];
+        int32_t cr[RW_CAND];
+        uint32_t cl[RW_CAND];
+#pragma unroll
+        for (int j = 0; j < RW_CAND; ++j) {
+            cu[j] = -INFINITY; cr[j] = 0; cl[j] = 0u;
+            const int i = j * 64 + lane;
+            if (j < nj && i < n) {
+                cu[j] = a.cand_scores[(int64_t)q * a.cap + i];
+                cr[j] = a.cand_idx[(int64_t)q * a.cap + i];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < RW_CAND; ++j) {
+            const int i = j * 64 + lane;
+            if (j < nj && i < n) {
+                if ((uint32_t)cr[j] >= (uint32_t)a.N) { cr[j] = 0; cu[j] = -INFINITY; }   // (reported by the refine launch)
+                const float strength = a.meta[(int64_t)cr[j] * 4];
+                float err = 0.5f * a.e_cos * fabsf(strength);
+                if (a.rho)
+                    err = 0.5f * fabsf(strength) * (a.rho[cr[j]] + a.e_fix + (strength < 0.0f ? 2.0f * a.eq_worst : eqq));
+                cl[j] = ord_key(cu[j] - 2.0f * err);
+            }
+        }
+        auto kth = [&](int kk) -> float {                    // kk-th largest L, -inf if there are fewer
+            if (kk <= 0 || n < kk) return -INFINITY;
+            uint32_t t = 0u;
+            for (int bit = 31; bit >= 0; --bit) {
+                const uint32_t cand = t | (1u << bit);
+                int c = 0;
+#pragma unroll
+                for (int j = 0; j < RW_CAND; ++j)
+                    if (j < nj) c += (int)__popcll(__ballot(j * 64 + lane < n && cl[j] >= cand));
+                if (c >= kk) t = cand;
+            }
+            return ord_unkey(t);
+        };
+        tk = kth(a.k);
+        tk2 = kth(k2);
+    }
+    if (lane == 0) { out[(int64_t)q * 2] = tk; out[(int64_t)q * 2 + 1] = tk2; }
+}
+
 template <int RF_ROWS, int RF_KC>
 __device__ __forceinline__ void refine_one_query(const RefineArgs& a, const int q) {
     extern __shared__ __attribute__((aligned(16))) char rsmem[];
@@ -1393,6 +1461,7 @@ __device__ __forceinline__ void refine_one_query(const RefineArgs& a, const int 
         }
         t2 = s_prefix;
     }
+    if (a.t2_ext) { const uint32_t e = ord_key(a.t2_ext[q]); t2 = e > t2 ? e : t2; }
     stamp(2);
     // ---- survivors: U >= T2 ----
     for (int i = tid; i < n; i += RF_THREADS) {
@@ -1405,7 +1474,7 @@ __device__ __forceinline__ void refine_one_query(const RefineArgs& a, const int 
     int S = s_ns;
     if (S > RF_SURV) { ovf = true; ovf_bits |= 8; S = RF_SURV; }
     if (ovf && tid == 0 && a.overflow) atomicOr(a.overflow, ovf_bits);   // which list overflowed
-    if (S == 0 && tid == 0 && a.overflow) atomicOr(a.overflow, AURA_KNN_FLAG_NO_CANDIDATES);   // (not an overflow)
+    if (S == 0 && (n == 0 || !a.t2_ext) && tid == 0 && a.overflow) atomicOr(a.overflow, AURA_KNN_FLAG_NO_CANDIDATES);   // (not an overflow)
     __syncthreads();     // candidate arrays are dead from here: rsmem is reused below
 
     // ---- exact re-scoring: rounds of 8 x RF_ROWS survivors, survivor base + 8 r + w -> wave w, slot r ----

@@ -813,18 +813,73 @@ class Ivf2Plan:
         return out_s, out_i, ovf
 
 
+class HostFlag:
+    """A host-mapped completion word for call chains that end in an entry point without one (the staged recall):
+    ``signal(flag_tensor)`` enqueues a one-thread launch that stores the flag and a sequence number;
+    ``wait()`` polls it and returns the flag -- no device-to-host copy, no stream synchronisation (a blocking wait
+    on a ~1 ms stream costs the host 1-2 ms on this runtime)."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        hw = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            check(lib().aura_host_word_alloc(ctypes.byref(hw)), "aura_host_word_alloc")
+        self._hw_ptr = hw.value
+        self._hw = (ctypes.c_uint32 * 2).from_address(hw.value)
+        self._seq = 0
+        self._flag = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_hw_ptr", None):
+                torch.cuda.synchronize(self.device)          # no launch may still hold the word
+                lib().aura_host_word_free(self._hw_ptr)
+                self._hw_ptr = None
+        except Exception:
+            pass
+
+    def signal(self, flag: torch.Tensor) -> None:
+        _need(flag, "flag", torch.int32)
+        self._seq = (self._seq + 1) & 0x7fffffff or 1
+        self._flag = flag
+        check(lib().aura_signal_flag(_p(flag), self._hw_ptr, self._seq, _stream()), "aura_signal_flag")
+
+    def wait(self, timeout_s: float = 5.0) -> int:
+        import time as _t
+        hw, seq = self._hw, self._seq
+        t_end, n = None, 0
+        while hw[1] != seq:
+            n += 1
+            if (n & 0xfff) == 0:                             # every ~4000 polls: give up after timeout_s
+                now = _t.perf_counter()
+                if t_end is None:
+                    t_end = now + timeout_s
+                elif now > t_end:
+                    return int(self._flag.item())             # (never seen: the ordinary read still works)
+        return int(hw[0])
+
+
 class Ivf2Staged:
-    """``knn_search_ivf2`` in two stages (``aura_knn_search_ivf2_staged``) for one pass of at most 8192 queries:
+    """``knn_search_ivf2`` in stages (``aura_knn_search_ivf2_staged``) for one pass of at most 8192 queries:
     ``stage1(k2)`` -> bounds [nq, 2] (the k-th and the k2-th largest sampled lower bound of every query on this
-    bank), ``stage2(bound [nq])`` -> (scores, idx, overflow flag) with every threshold raised to ``bound`` first.
-    Between the two calls the caller combines the bounds of all shards of a row-sharded bank; nothing else may
-    use this stream's kNN workspace in between."""
+    bank), ``stage2(bound [nq])`` -> (scores, idx, overflow flag) with every threshold raised to ``bound`` first --
+    or ``stage2_bounds(bound, k2)`` -> the filtered candidates' own bounds [nq, 2] and ``stage3(bound2 [nq])`` -> the
+    result re-scored only where a candidate can still reach ``bound2``.  Between the calls the caller combines the
+    bounds of all shards of a row-sharded bank; nothing else may use this stream's kNN workspace in between."""
 
     MAX_QUERIES = 8192
 
     def __init__(self, bank, inv_norm, meta, queries, k: int, now: float, centroids, nprobe: int,
                  sorted_shadow, rho, sorted_rows, pad_off, list_len, idx_base: int = 0,
-                 n_sorted: Optional[int] = None, lists_flag=None, probe_ids=None, row_constants=None):
+                 n_sorted: Optional[int] = None, lists_flag=None, probe_ids=None, row_constants=None,
+                 out=None, validated: bool = False):
+        """``out``: (scores [nq, k] fp32, idx [nq, k] int32) to write into (contiguous; e.g. slices of the caller's
+        result); ``validated``: the caller has run this constructor's checks on the same tensors before (a pass of a
+        multi-pass recall, or the next call on an unchanged bank) -- only the per-call shapes are checked."""
+        if validated:
+            self._init_fast(bank, inv_norm, meta, queries, k, now, centroids, nprobe, sorted_shadow, rho, sorted_rows,
+                            pad_off, list_len, idx_base, n_sorted, lists_flag, probe_ids, row_constants, out)
+            return
         _need(bank, "bank", torch.float32); _need(inv_norm, "inv_norm", torch.float32)
         _need(meta, "meta", torch.float32); _need(queries, "queries", torch.float32)
         _need(centroids, "centroids", torch.float32); _need(sorted_shadow, "sorted_shadow", torch.bfloat16)
@@ -852,23 +907,48 @@ class Ivf2Staged:
             _need(probe_ids, "probe_ids", torch.int32)
             if tuple(probe_ids.shape) != (nq, 8):
                 raise ValueError("Ivf2Staged: probe_ids must be [nq, 8]")
+        self._init_fast(bank, inv_norm, meta, queries, k, now, centroids, nprobe, sorted_shadow, rho, sorted_rows, pad_off,
+                        list_len, idx_base, ns, lists_flag, probe_ids, row_constants, out)
+
+    def _init_fast(self, bank, inv_norm, meta, queries, k, now, centroids, nprobe, sorted_shadow, rho, sorted_rows,
+                   pad_off, list_len, idx_base, n_sorted, lists_flag, probe_ids, row_constants, out):
+        M, D = bank.shape
+        nq = queries.shape[0]
+        ns = sorted_rows.numel() if n_sorted is None else int(n_sorted)
+        if not (queries.is_cuda and queries.dtype == torch.float32 and queries.dim() == 2 and queries.shape[1] == D
+                and queries.is_contiguous() and 0 < nq <= self.MAX_QUERIES):
+            raise ValueError("Ivf2Staged: queries must be a contiguous fp32 [1..8192, D] tensor on the bank's device")
+        if probe_ids is not None and not (probe_ids.is_cuda and probe_ids.dtype == torch.int32 and
+                                          tuple(probe_ids.shape) == (nq, 8) and probe_ids.is_contiguous()):
+            raise ValueError("Ivf2Staged: probe_ids must be a contiguous int32 [nq, 8] tensor")
         dev = bank.device
         self._keep = (bank, inv_norm, meta, queries, centroids, sorted_shadow, rho, sorted_rows, pad_off, list_len,
                       lists_flag, probe_ids, row_constants)
         self.nq, self.k = nq, int(k)
-        self.out_s = torch.empty(nq, k, dtype=torch.float32, device=dev)
-        self.out_i = torch.empty(nq, k, dtype=torch.int32, device=dev)
+        if out is None:
+            self.out_s = torch.empty(nq, k, dtype=torch.float32, device=dev)
+            self.out_i = torch.empty(nq, k, dtype=torch.int32, device=dev)
+        else:
+            self.out_s, self.out_i = out
+            if not (self.out_s.is_contiguous() and self.out_i.is_contiguous() and tuple(self.out_s.shape) == (nq, k)
+                    and tuple(self.out_i.shape) == (nq, k) and self.out_s.dtype == torch.float32
+                    and self.out_i.dtype == torch.int32 and self.out_s.device == dev and self.out_i.device == dev):
+                raise ValueError("Ivf2Staged: out must be contiguous (fp32 [nq, k], int32 [nq, k]) on the bank's device")
         self.ovf = _overflow_flag(dev)
         L = lib()
         self._nbytes = L.aura_knn_ivf2_workspace_bytes(ns, nq, k)
         self._ws = _workspace(dev, self._nbytes)
         base = (self._ws.data_ptr() + 255) // 256 * 256
-        self._call = lambda stage, k2, bounds: check(
-            L.aura_knn_search_ivf2_staged(_p(bank), _p(inv_norm), _p(meta), _p(sorted_shadow), _p(rho), _p(sorted_rows),
-                                          _p(pad_off), _p(list_len), _p(lists_flag), _p(row_constants), ns, M,
-                                          _p(queries), now, D, nq, k, _p(centroids), nprobe, _p(probe_ids), idx_base,
-                                          _p(self.out_s), _p(self.out_i), base, self._nbytes, _p(self.ovf), stage, k2,
-                                          _p(bounds), _stream()), "aura_knn_search_ivf2_staged")
+        # (a plain tuple, not a closure over self: a self-referencing lambda made every staged pass a reference cycle
+        #  that only the cyclic collector freed -- with its 2-MB result views -- and the allocator answered the pile-up
+        #  with fresh hipMallocs: recalls of 1.2 ms read 1.6-3.4 ms at random)
+        self._args = (_p(bank), _p(inv_norm), _p(meta), _p(sorted_shadow), _p(rho), _p(sorted_rows), _p(pad_off),
+                      _p(list_len), _p(lists_flag), _p(row_constants), ns, M, _p(queries), now, D, nq, k, _p(centroids),
+                      nprobe, _p(probe_ids), idx_base, _p(self.out_s), _p(self.out_i), base, self._nbytes, _p(self.ovf))
+
+    def _call(self, stage: int, k2: int, bounds) -> None:
+        check(lib().aura_knn_search_ivf2_staged(*self._args, stage, k2, _p(bounds), _stream()),
+              "aura_knn_search_ivf2_staged")
 
     def stage1(self, k2: int = 0) -> torch.Tensor:
         b = torch.empty(self.nq, 2, dtype=torch.float32, device=self.out_s.device)
@@ -880,6 +960,28 @@ class Ivf2Staged:
         if bound.numel() != self.nq:
             raise ValueError("Ivf2Staged.stage2: one bound per query")
         self._call(2, 0, bound)
+        return self.out_s, self.out_i, self.ovf
+
+    def stage2_bounds(self, bound: torch.Tensor, k2: int) -> torch.Tensor:
+        """Stage 2 up to the filter scan, then the CANDIDATES' bounds [nq, 2] (the k-th and the k2-th largest lower
+        bound among this bank's candidates, -inf where there are fewer) instead of the refine: for a second, much
+        tighter combination over the shards, consumed by ``stage3``."""
+        _need(bound, "bound", torch.float32)
+        if bound.numel() != self.nq:
+            raise ValueError("Ivf2Staged.stage2_bounds: one bound per query")
+        b = torch.empty(self.nq, 2, dtype=torch.float32, device=self.out_s.device)
+        b.view(-1)[: self.nq].copy_(bound.reshape(-1))     # in: one bound per query; out: [nq, 2]
+        self._call(4, int(k2), b)
+        return b
+
+    def stage3(self, bound: torch.Tensor):
+        """The refine against a lower bound of every query's k-th best score over ALL shards: candidates whose
+        upper bound stays below it are not re-scored (rows of this bank's top k that cannot be in the global top k
+        come back as -1)."""
+        _need(bound, "bound", torch.float32)
+        if bound.numel() != self.nq:
+            raise ValueError("Ivf2Staged.stage3: one bound per query")
+        self._call(3, 0, bound)
         return self.out_s, self.out_i, self.ovf
 
 

@@ -334,6 +334,10 @@ int aura_knn_search_ivf2_probed(const float* bank, const float* inv_norm, const 
  * hippocampal.py's retrieval is synchronous too, every .item() in :311-317 waits for the GPU.) */
 int aura_host_word_alloc(void** host_word_out);
 int aura_host_word_free(void* host_word);
+/* The completion signal of aura_knn_search_ivf2_signal on its own: a one-thread launch on `stream` stores *flag_dev
+ * (0 if NULL) into host_word[0], then host_seq into host_word[1].  For call chains that end in another entry point
+ * (the staged recall): poll instead of a stream synchronisation. */
+int aura_signal_flag(const int32_t* flag_dev, uint32_t* host_word, uint32_t host_seq, void* stream);
 int aura_knn_search_ivf2_signal(const float* bank, const float* inv_norm, const float* meta,
                                 const uint16_t* sorted_bf16, const float* rho, const int32_t* sorted_rows,
                                 const int32_t* pad_off, const int32_t* list_len, const int32_t* lists_flag,
@@ -343,7 +347,7 @@ int aura_knn_search_ivf2_signal(const float* bank, const float* inv_norm, const 
                                 float* out_scores, int32_t* out_idx, void* workspace, int64_t workspace_bytes,
                                 int32_t* overflow_out, uint32_t* host_word, uint32_t host_seq, void* stream);
 
-/* aura_knn_search_ivf2[_probed] in two stages, for a bank that is row-sharded over ranks: the
+/* aura_knn_search_ivf2[_probed] in stages, for a bank that is row-sharded over ranks: the
  * prefilter's threshold of a query is a lower bound of its k-th best score, and bounds found on different
  * shards can be combined before any shard filters -- every shard then keeps about 1/S of the candidates
  * and survivors it would keep against its own bound.
@@ -353,6 +357,13 @@ int aura_knn_search_ivf2_signal(const float* bank, const float* inv_norm, const 
  *   stage 2: same arguments, same workspace (untouched in between), bounds[q] = ONE float per query: any valid
  *            lower bound of the query's global k-th best score, e.g. max(max over shards of bounds[.][0],
  *            min over shards of bounds[.][1]) with S k2 >= k; thresholds are raised to it, then filter + refine.
+ *   stage 4 + stage 3 (instead of stage 2, a second combination over the shards): stage 4 is stage 2 up to the
+ *            filter scan; bounds (room for [nq][2]) carries the combined bound in its first nq floats on entry and
+ *            the FILTERED CANDIDATES' bounds on return -- bounds[q][0] = the k-th, [q][1] = the k2-th largest lower
+ *            bound among this bank's candidates of query q (-inf where there are fewer).  Combined like stage 1's
+ *            they are close to the global k-th best score itself.  Stage 3: bounds[q] = that combination (one
+ *            float per query); the refine re-scores only candidates whose upper bound reaches it, so a shard
+ *            returns the rows of its top k that can be in the global top k and -1 for the rest.
  * probe_ids may be NULL (probes computed in stage 1).  nq <= 8192 per staged call. */
 int aura_knn_search_ivf2_staged(const float* bank, const float* inv_norm, const float* meta,
                                 const uint16_t* sorted_bf16, const float* rho, const int32_t* sorted_rows,

@@ -117,8 +117,30 @@ def test_staged_inverted_list_recall_equals_unstaged(dev):
             calls.append(b.shape[0])
             return make(b).contiguous()
         s1, r1 = hf.recall_batch(qd, k=20, now=now, bound_exchange=(fn, 4))
-        assert calls == [2500], calls
+        assert calls == [2500, 2500], calls                        # sampled bounds, then the candidates' bounds
         assert torch.equal(r1, r0) and torch.equal(s1, s0), name
+    # a bound from outside ABOVE the bank's own k-th best score (other shards hold better rows): the second exchange
+    # hands it to the refine, which returns the rows that can still reach it -- a prefix of the unstaged result, at
+    # least the ten rows that score at least the bound, -1 behind it -- and re-scores far fewer candidates
+    b10 = s0[:, 9].clone()
+    state = {"n": 0}
+
+    def fn10(b):
+        state["n"] += 1
+        return (b[:, 0] if state["n"] == 1 else torch.maximum(b[:, 0], b10)).contiguous()
+    s2, r2 = hf.recall_batch(qd, k=20, now=now, bound_exchange=(fn10, 4))
+    assert state["n"] == 2
+    valid = r2 >= 0
+    # the ten rows that score at least the bound survive, in place; behind them come the rows whose UPPER bound
+    # still reaches it (a subset of the unstaged result, same score bits, ranked among themselves), then -1
+    assert torch.equal(r2[:, :10], r0[:, :10]) and torch.equal(s2[:, :10], s0[:, :10])
+    # (a survivor below the bound need not be one of the bank's own top 20 -- 20 better rows exist -- but it scores
+    #  below the bound, i.e. below the global k-th best, and never reaches the merged result)
+    below = s2[:, 10:][valid[:, 10:]]
+    assert bool((below <= b10.unsqueeze(1).expand(-1, 10)[valid[:, 10:]]).all())
+    sv = torch.where(valid, s2, torch.full_like(s2, -3.0e38))
+    assert bool((sv[:, :-1] >= sv[:, 1:]).all()), "sorted, valid entries first"
+    assert float(valid.float().sum(dim=1).mean()) < 19.5, "the external bound did not prune"
     # staged passes of 8192: 9000 queries -> two exchanges
     q9 = torch.cat([qd, qd, qd, qd[:1500]]).contiguous()
     calls = []
@@ -127,9 +149,9 @@ def test_staged_inverted_list_recall_equals_unstaged(dev):
         calls.append(b.shape[0])
         return b[:, 0].contiguous()
     s9, r9 = hf.recall_batch(q9, k=20, now=now, bound_exchange=(fn9, 1))
-    assert calls == [8192, 808]
+    assert calls == [8192, 8192, 808, 808]
     assert torch.equal(r9[:2500], r0) and torch.equal(s9[7500:], s0[:1500])
     # another path (exact recall) still performs the exchanges, with neutral bounds
     calls = []
     hf.recall_batch(qd, k=20, now=now, use_candidates=False, bound_exchange=(fn9, 1))
-    assert calls == [2500]
+    assert calls == [2500, 2500]

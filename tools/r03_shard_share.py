@@ -22,13 +22,13 @@ for S in (1, 2, 8):
     nq = 2048 * S
     q = torch.randn(nq, D, generator=g, device=dev)
     ids = hf.probe(q)
-    t_own = timed_wall(lambda: hf.recall_batch(q, k=k, now=now, probe_ids=ids, fallback_empty=False), 10, warm=2)
+    t_own = timed_wall(lambda: hf.recall_batch(q, k=k, now=now, probe_ids=ids, fallback_empty=False), 20, warm=5)
     line = f"S={S}: {rows} rows x {nq} queries: own bound {t_own * 1e3:.3f} ms"
     if S > 1:
         def fn(b):
             return torch.maximum(b[:, 0], b[:, 1]).contiguous()
         t_ex = timed_wall(lambda: hf.recall_batch(q, k=k, now=now, probe_ids=ids, fallback_empty=False,
-                                                  bound_exchange=(fn, S)), 10, warm=2)
+                                                  bound_exchange=(fn, S)), 20, warm=5)
         line += f", exchanged bound (emulated) {t_ex * 1e3:.3f} ms -> {2048 * S / t_ex:.3e} retrievals/s per step of all ranks"
     print(line, flush=True)
     del hf
