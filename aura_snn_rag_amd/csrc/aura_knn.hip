@@ -3134,7 +3134,7 @@ static int knn_search_ivf2_impl(const float* bank, const float* inv_norm, const 
         // the probe launch also fills the per-list query lists (lq_cnt / lq_list); probes that the caller
         // already has (a sharded bank computes them once per query, not once per rank) only fill the lists
         if (probe_ids) {
-            hipLaunchKernelGGL(ivf2_lists_from_ids_kernel, dim3((unsigned)((nqb * 8 + 255) / 256)), dim3(256), 0, s,
+            hipLaunchKernelGGL(ivf2_lists_from_ids_kernel, dim3((unsigned)((nqb * 8 + 256 * LFI_PER - 1) / (256 * LFI_PER))), dim3(256), 0, s,
                                probe_ids + qb0 * 8, nqb, nprobe, w.lq_cnt, w.lq_list);
             if ((rc = check_launch())) return rc;
         } else if ((rc = launch_probe(centroids, qptr, D, nqb, nprobe, w.probe_dist, w.probe, w.probe_ids, s,

@@ -1,0 +1,5 @@
+#!/bin/bash
+mkdir -p gpurun_out/r03
+timeout -k 10 800 python -m pytest tests/test_gpu_sharded_r03.py tests/test_gpu_scale.py tests/test_gpu_knn.py tests/test_gpu_knn_r03.py -m gpu -x -q > gpurun_out/r03/t19.log 2>&1; rc=$?; echo "pytest rc $rc" >> gpurun_out/r03/t19.log; tail -3 gpurun_out/r03/t19.log | cut -c1-200
+[ $rc -eq 0 ] || { grep -n "Error\|assert \|FAILED\|error" gpurun_out/r03/t19.log | head -20; exit 1; }
+timeout -k 10 300 python tools/r03_shard_share.py 2>&1 | grep -v amdgpu | tail -3
