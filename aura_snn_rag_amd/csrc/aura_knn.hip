@@ -3092,7 +3092,7 @@ static int knn_search_ivf2_impl(const float* bank, const float* inv_norm, const 
             fflush(stderr);
         }
     };
-    const int stiles = ivf2_stiles(n_sorted);                // sample tiles per list
+    const int stiles = ivf2_stiles(n_sorted, k, stg != 0);   // sample tiles per list (fewer when a bound from outside follows)
     static const bool w4 = getenv("AURA_CS_WAVES4") != nullptr;   // A/B runs: one wave per SIMD
     // AURA_IVF_WG4: TWO independent four-wave workgroups per CU, 128 query slots per block (round-3 experiment)
     static const bool wg4 = !w4 && getenv("AURA_IVF_WG4") != nullptr;
@@ -3185,7 +3185,9 @@ static int knn_search_ivf2_impl(const float* bank, const float* inv_norm, const 
             const dim3 tg((unsigned)((nqb + 3) / 4)), tb(256);
 #define AURA_THR2(PER) hipLaunchKernelGGL((ivf2_threshold_kernel<PER>), tg, tb, 0, s, w.gmax, w.qslot, w.blk_list, list_len, \
                                           nprobe, k, nqb, w.thr, w.cnt, stg == 1 ? k2 : 0, stg == 1 ? bounds : nullptr, bsh)
-            if (stiles == 32) AURA_THR2(8);
+            if (stiles == 8) AURA_THR2(2);
+            else if (stiles == 16) AURA_THR2(4);
+            else if (stiles == 32) AURA_THR2(8);
             else if (stiles == 64) AURA_THR2(16);
             else if (stiles == 128) AURA_THR2(32);
             else AURA_THR2(64);

@@ -20,18 +20,26 @@
 // Results are bit-identical to aura_knn_search_ivf and to the masked scans (same candidate sets,
 // same fp32 arithmetic, ties to the lower row).
 
-constexpr int IVF2_STILES = 32;            // sample tiles (of 16 rows) per list, at least
+constexpr int IVF2_STILES = 8;             // sample tiles (of 16 rows) per list, at least
 constexpr int IVF2_STILES_MAX = 256;       // ... and at most
-// Sample tiles per list for a sorted shadow of n_sorted rows (slack included): at least a twelfth of an
-// average list, so that the k-th best of the sample sits near rank 8..12 k of the probed rows whatever the
-// bank's size -- with a fixed 32 tiles a 10 M-row bank's queries collected more candidates than the refine
-// stage holds and every call fell back to the fp32 lists -- a power of two in [32, 256].  (At 1 M rows 64
-// tiles instead of 32 cost 35 us more in the sample scan and threshold launches and saved 15 in the refine.)
-static inline int ivf2_stiles(int64_t n_sorted) {
-    static const int forced = getenv("AURA_IVF_STILES") ? atoi(getenv("AURA_IVF_STILES")) : 0;   // tuning runs: 32/64/128/256
-    if (forced == 32 || forced == 64 || forced == 128 || forced == 256) return forced;
+// Sample tiles per list for a sorted shadow of n_sorted rows (slack included) and top-k: a power of two in [8, 256],
+//   * at least a twelfth of an average list, so that the k-th best of the sample sits near rank 8..12 k of the
+//     probed rows whatever the bank's size -- with a fixed 32 tiles a 10 M-row bank's queries collected more
+//     candidates than the refine stage holds and every call fell back to the fp32 lists.  (At 1 M rows 64 tiles
+//     instead of 32 cost 35 us more in the sample scan and threshold launches and saved 15 in the refine.)
+//   * at least k / 8 (a query's eight lists then hold 16 x tiles >= 2 k sampled 8-row groups: the k-th largest
+//     group maximum exists with room to spare; k = 256 -> 32 tiles, the floor of rounds 1-3a for every k);
+//   * no more than that for SHORT lists: with the old floor of 32 a 125 000-row shard of the 8-rank layout (30 tiles
+//     per list) was sampled in full -- the sample scan did the filter scan's work once more (109 of a pass's 480 us).
+//     (Only where a bound from outside prunes the refine -- the staged recall of a sharded bank, `exchanged`: a
+//     bank on its own pays for the looser threshold in the refine, 1.53 -> 2.05 ms at 125 000 rows x 16 384 queries,
+//     and keeps the floor of 32.)
+static inline int ivf2_stiles(int64_t n_sorted, int k, bool exchanged = false) {
+    static const int forced = getenv("AURA_IVF_STILES") ? atoi(getenv("AURA_IVF_STILES")) : 0;   // tuning runs: 8 .. 256
+    int st = exchanged ? IVF2_STILES : 32;
+    while (st < IVF2_STILES_MAX && 8 * st < k) st *= 2;
+    if (forced == 8 || forced == 16 || forced == 32 || forced == 64 || forced == 128 || forced == 256) return forced > st ? forced : st;
     const int64_t avg_tiles = n_sorted / 16 / 256;
-    int st = IVF2_STILES;
     while (st < IVF2_STILES_MAX && (int64_t)st * 12 < avg_tiles) st *= 2;
     return st;
 }
@@ -404,7 +412,7 @@ static Ivf2Workspace carve_ivf2(void* base, int64_t Npad, int64_t nq, int k) {
     w.thr = reinterpret_cast<uint32_t*>(take(mb * 256 * 4));
     w.eq_slot = reinterpret_cast<float*>(take(mb * 256 * 4));
     w.eq_q = reinterpret_cast<float*>(take(qp * 4));
-    w.gmax = reinterpret_cast<float*>(take(mb * 256 * 2 * ivf2_stiles(Npad) * 4));
+    w.gmax = reinterpret_cast<float*>(take(mb * 256 * 2 * ivf2_stiles(Npad, k) * 4));
     w.qhat = reinterpret_cast<uint16_t*>(take((qp + 1) * 768 * 2));   // one fragment set per query + the zero entry
     w.rowc = reinterpret_cast<float4*>(take((Npad > 0 ? Npad : 1) * 16));
     w.heavy = reinterpret_cast<int32_t*>(take((qp + 1) * 4));
