@@ -38,14 +38,24 @@ def main():
             hf.recall_batch(q, k=k, now=now)
         torch.cuda.synchronize()
         ks = []
-        for rep in range(3):
-            lib.aura_profile_begin(30 * 16)
-            for _ in range(30):
-                hf.recall_batch(q, k=k, now=now)
-            torch.cuda.synchronize()
-            buf = (ctypes.c_float * (30 * 16))()
-            n = lib.aura_profile_end(buf, 30 * 16)
-            ks.append(sum(buf[j] for j in range(n)) / max(n, 1))
+        flagsets = [int(x) for x in os.environ.get("AURA_PROBE_FLAGS", "0").split(",")]
+        per_flag = {}
+        for fl in flagsets:
+            lib.aura_debug_cs_flags(fl)
+            ks = []
+            for rep in range(3):
+                lib.aura_profile_begin(30 * 16)
+                for _ in range(30):
+                    hf.recall_batch(q, k=k, now=now)
+                torch.cuda.synchronize()
+                buf = (ctypes.c_float * (30 * 16))()
+                n = lib.aura_profile_end(buf, 30 * 16)
+                ks.append(sum(buf[j] for j in range(n)) / max(n, 1))
+            per_flag[fl] = statistics.median(ks)
+        lib.aura_debug_cs_flags(0)
+        if len(flagsets) > 1:
+            print(f"bank {it}: kernel ms per flag set " + ", ".join(f"{fl}: {v:.4f}" for fl, v in per_flag.items()), flush=True)
+        ks = [per_flag[flagsets[0]]]
         iv = hf._ivf
         ptrs = {"sorted_bf16": iv.sorted_bf16.data_ptr(), "bank": hf.memory_features.data_ptr(),
                 "rowc": iv.rowc.data_ptr() if getattr(iv, "rowc", None) is not None else 0}
