@@ -137,6 +137,11 @@ def test_config4_shard_shape_vs_oracle(dev):
 # The row-sharded bank on real kernels: two processes share the one GPU of the test box and talk
 # through gloo (RCCL refuses two ranks on one device); every rank drives the HIP library.
 # ----------------------------------------------------------------------------------------------
+def _sharded_rows(world):
+    # every shard must hold at least 8192 rows for the two-stage (and hence the staged, bound-exchanging) recall
+    return 20000 if world == 2 else 12000 * world - 2000
+
+
 def _sharded_gpu_worker(rank, world, port, out):
     import os
     import torch.distributed as dist
@@ -146,25 +151,26 @@ def _sharded_gpu_worker(rank, world, port, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     dev = torch.device("cuda:0")
-    D, M = 64, 24000
+    D, M, NF = 64, 12000 * world, _sharded_rows(world)
     g = torch.Generator().manual_seed(31)
     centres = torch.randn(300, D, generator=g) * 3
-    feats = centres[torch.randint(0, 300, (20000,), generator=g)] + torch.randn(20000, D, generator=g)
+    feats = centres[torch.randint(0, 300, (NF,), generator=g)] + torch.randn(NF, D, generator=g)
     extra = centres[torch.randint(0, 300, (300,), generator=g)] + torch.randn(300, D, generator=g)
     q = centres[torch.randint(0, 300, (700,), generator=g)] + torch.randn(700, D, generator=g)
-    perm = torch.randperm(20000, generator=g)
+    perm = torch.randperm(NF, generator=g)
     local = HippocampalFormation(feature_dim=D, max_memories=M // world, n_place_cells=8, n_time_cells=4,
                                  n_grid_cells=4, device="cuda", use_centroid_index=True, overflow="fifo")
     local.centroids_update_interval = 10 ** 9
     now = [1.7e9]
     sh = ShardedHippocampus(local, M, now_fn=lambda: now[0])
-    for i in range(0, 20000, 7000):                                   # batches straddle the shard boundary at 12000
-        sh.write([f"m{j}" for j in range(i, min(i + 7000, 20000))], feats[i:i + 7000])
+    for i in range(0, NF, 7000):                                      # batches straddle the shard boundaries (12000 rows each)
+        sh.write([f"m{j}" for j in range(i, min(i + 7000, NF))], feats[i:i + 7000])
     sh.rebuild_centroids(perm=perm)
     sh.write([f"x{j}" for j in range(300)], extra)                    # online centroid updates on the replicas
     s_c, r_c = sh.recall_batch(q.to(dev), k=9, now=now[0])            # > 512 queries: inverted lists per shard
     s_e, r_e = sh.recall_batch(q.to(dev), k=9, now=now[0], use_candidates=False)
-    myq = q[rank * 350:(rank + 1) * 350].to(dev).contiguous()
+    per = 700 // world
+    myq = q[rank * per:(rank + 1) * per].to(dev).contiguous()
     s_o, r_o = sh.recall_batch(myq, k=9, now=now[0], all_gather_queries=True)
     torch.save(dict(count=sh.memory_count, local=local.memory_count, cent=local.centroids.cpu(), exchanges=sh.exchanges,
                     res=[t.cpu() for t in (s_c, r_c, s_e, r_e)], own=(s_o.cpu(), r_o.cpu()),
@@ -173,39 +179,41 @@ def _sharded_gpu_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_sharded_bank_on_hip_kernels_two_ranks_one_gpu(dev, tmp_path):
+@pytest.mark.parametrize("world", [2, 4])      # 4 shards: the bound exchanges run with k2 = ceil(9 / 4) = 3
+def test_sharded_bank_on_hip_kernels_two_ranks_one_gpu(dev, tmp_path, world):
     import socket
     import torch.multiprocessing as mp
     from aura_snn_rag_amd.core.hippocampal import HippocampalFormation
     s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
     out = str(tmp_path / "shgpu")
     mp.get_context("spawn")
-    mp.spawn(_sharded_gpu_worker, args=(2, port, out), nprocs=2, join=True)
-    parts = [torch.load(out + f".{r}") for r in range(2)]
+    mp.spawn(_sharded_gpu_worker, args=(world, port, out), nprocs=world, join=True)
+    parts = [torch.load(out + f".{r}") for r in range(world)]
     # the same operations on ONE bank
-    D, M = 64, 24000
+    D, M, NF = 64, 12000 * world, _sharded_rows(world)
     g = torch.Generator().manual_seed(31)
     centres = torch.randn(300, D, generator=g) * 3
-    feats = centres[torch.randint(0, 300, (20000,), generator=g)] + torch.randn(20000, D, generator=g)
+    feats = centres[torch.randint(0, 300, (NF,), generator=g)] + torch.randn(NF, D, generator=g)
     extra = centres[torch.randint(0, 300, (300,), generator=g)] + torch.randn(300, D, generator=g)
     q = centres[torch.randint(0, 300, (700,), generator=g)] + torch.randn(700, D, generator=g)
-    perm = torch.randperm(20000, generator=g)
+    perm = torch.randperm(NF, generator=g)
     from aura_snn_rag_amd.core import hippocampal as H
     hf = HippocampalFormation(feature_dim=D, max_memories=M, n_place_cells=8, n_time_cells=4, n_grid_cells=4,
                               device="cuda", use_centroid_index=True, overflow="fifo")
     hf.centroids_update_interval = 10 ** 9
-    hf.create_episodic_memories([f"m{j}" for j in range(20000)], feats)
+    hf.create_episodic_memories([f"m{j}" for j in range(NF)], feats)
     hf.rebuild_centroids(perm=perm)
     hf.create_episodic_memories([f"x{j}" for j in range(300)], extra)
     hf.memory_metadata[:, 1] = 1.7e9                                  # the sharded run's clock
     s_c, r_c = hf.recall_batch(q, k=9, now=1.7e9)
     s_e, r_e = hf.recall_batch(q, k=9, now=1.7e9, use_candidates=False)
-    assert parts[0]["count"] == 20300 and [p["local"] for p in parts] == [12000, 8300]
+    R, total = M // world, NF + 300
+    assert parts[0]["count"] == total and [p["local"] for p in parts] == [max(0, min(R, total - r * R)) for r in range(world)]
     assert all(p["exchanges"] >= 2 for p in parts), "the shards' bounds were not exchanged"
-    assert torch.equal(parts[0]["cent"], parts[1]["cent"])
+    assert all(torch.equal(parts[0]["cent"], p["cent"]) for p in parts[1:])
     assert torch.allclose(parts[0]["cent"], hf.centroids.cpu(), rtol=1e-5, atol=1e-5)
     meta = torch.cat([p["meta"] for p in parts])
-    agree = (meta[:20300, 2] == hf.memory_metadata[:20300, 2].cpu()).float().mean().item()
+    agree = (meta[:total, 2] == hf.memory_metadata[:total, 2].cpu()).float().mean().item()
     assert agree >= 0.999, f"centroid ids: {agree}"
     ps_c, pr_c, ps_e, pr_e = parts[0]["res"]
     assert torch.equal(pr_e, r_e.cpu()) and torch.equal(ps_e, s_e.cpu())       # exact recall: bit-identical
@@ -214,9 +222,10 @@ def test_sharded_bank_on_hip_kernels_two_ranks_one_gpu(dev, tmp_path):
     else:                                                                       # centroids differ in the last bits:
         same = (pr_c == r_c.cpu()).all(dim=1).float().mean().item()              # a probe may flip for a few queries
         assert same >= 0.97, same
-    for r in range(2):
+    per = 700 // world
+    for r in range(world):
         s_o, r_o = parts[r]["own"]
-        assert torch.equal(r_o, pr_c[r * 350:(r + 1) * 350])
+        assert torch.equal(r_o, pr_c[r * per:(r + 1) * per])
 
 
 @pytest.mark.parametrize("N", [2_500_000, 4_200_000, 6_000_000])     # 64 / 128 / 256 sample tiles per list
