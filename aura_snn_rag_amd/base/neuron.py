@@ -6,9 +6,10 @@ arguments, buffer names (``a,b,c,d,dt`` / ``params`` / ``beta,threshold,slope``)
 (``neuron.py:186-196``, ``:237-248``) and the per-step eager ops of the LIF (``:135-137``) run as
 ONE kernel launch each (``aura_snn_rag_amd/csrc/aura_neuron.hip``).
 
-Forward only: the kernels do not record autograd history.  An input that requires grad raises
-(surrogate-gradient backward kernels are SURVEY.md section 8f item 4).  Tensors must live on the
-HIP device; there is no CPU path.
+Izhikevich / AdEx: the spikes are a comparison in the reference and carry no autograd history there either; the
+loops accept inputs that require grad and return history-free spikes.  The LIF records through its learnable
+surrogate (``LifStepFunction``: ``aura_lif_train_forward`` / ``aura_lif_backward``, fp32 and bf16) exactly when the
+reference would build a graph.  Tensors must live on the HIP device; there is no CPU path.
 """
 from __future__ import annotations
 

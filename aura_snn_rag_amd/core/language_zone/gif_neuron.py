@@ -11,10 +11,11 @@ registers.  The dense ``nn.Linear`` stays a library GEMM on the matrix cores.  f
 bf16 each op rounds to bf16 exactly as the reference's bf16 tensors do.
 
 Training: when autograd is recording (grad mode on and the input, a parameter or the state
-requires grad) the fp32 loop runs as ``aura_gif_train_forward`` and its gradient as
-``aura_gif_backward`` -- BPTT through the T steps with the triangular surrogate of
+requires grad) the loop runs as ``aura_gif_train_forward[_bf16]`` and its gradient as
+``aura_gif_backward[_bf16]`` -- BPTT through the T steps with the triangular surrogate of
 ``MultiBitSurrogate`` -- wrapped in ``GifLoopFunction``; the ``nn.Linear`` around it is ordinary
-autograd.  bf16 is inference-only.
+autograd.  In bf16 the recording forward is the per-op-rounded inference loop bit for bit and the backward is the
+fp32 chain evaluated on the forward's bf16-rounded intermediates (``csrc/aura_train.hip``).
 """
 from __future__ import annotations
 
